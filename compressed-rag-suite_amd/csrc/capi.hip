@@ -1,0 +1,205 @@
+// capi.hip -- the extern "C" surface declared in include/crs_hip.h.
+#include "../../include/crs_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "scan.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "") {
+  snprintf(g_err, sizeof g_err, fmt, detail);
+  return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof g_err, "%s: %s", where, hipGetErrorString(e));
+  return CRS_EHIP;
+}
+
+int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    cus[dev] = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+constexpr int kWgPerCu = 2;
+
+struct Plan {
+  int pdim, tile_rows, n_tiles, nwg;
+  size_t part_elems;  // nwg * nq * k
+};
+
+int make_plan(int nq, int dim, int k, int64_t n_rows, Plan* p) {
+  if (nq <= 0 || dim <= 0 || dim > 1024) return fail(CRS_EINVAL, "nq must be > 0 and 0 < dim <= 1024");
+  if (k <= 0 || k > CRS_MAX_K) return fail(CRS_EINVAL, "k must be in 1..CRS_MAX_K");
+  if (n_rows <= 0 || n_rows > 0x7fffffffLL - 64) return fail(CRS_EINVAL, "n_rows must be in 1..2^31-65");
+  const int cus = device_cus();
+  if (cus <= 0) return fail(CRS_EHIP, "no HIP device available%s");
+  p->pdim = crs_padded_dim(dim);
+  p->tile_rows = crs::scan_tile_rows(p->pdim);
+  p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
+  const int cap = cus * kWgPerCu;
+  p->nwg = p->n_tiles < cap ? p->n_tiles : cap;
+  p->part_elems = (size_t)p->nwg * nq * k;
+  return CRS_OK;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+const char* crs_last_error(void) { return g_err; }
+int crs_abi_version(void) { return 1; }
+int crs_padded_dim(int dim) { return dim <= 0 ? 0 : (dim + 127) / 128 * 128; }
+
+int crs_slab_append_f32(const float* emb_dev, int64_t n, int dim, int slab_type, void* slab_dev,
+                        float* scales_dev, float* shadow_f32_dev, int64_t row0, void* stream) {
+  if (n < 0 || dim <= 0 || dim > 1024 || row0 < 0) return fail(CRS_EINVAL, "bad n/dim/row0");
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
+  if (n == 0) return CRS_OK;
+  if (!emb_dev || !slab_dev) return fail(CRS_EINVAL, "null pointer");
+  if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
+  const int e = crs::slab_append_launch(emb_dev, n, dim, crs_padded_dim(dim), slab_type, slab_dev,
+                                        scales_dev, shadow_f32_dev, row0, (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "slab_append") : CRS_OK;
+}
+
+int crs_queries_to_f16(const float* q_dev, int nq, int dim, void* q16_dev, void* stream) {
+  if (nq < 0 || dim <= 0 || dim > 1024) return fail(CRS_EINVAL, "bad nq/dim");
+  if (nq == 0) return CRS_OK;
+  if (!q_dev || !q16_dev) return fail(CRS_EINVAL, "null pointer");
+  const int e = crs::queries_to_f16_launch(q_dev, nq, dim, crs_padded_dim(dim),
+                                           reinterpret_cast<_Float16*>(q16_dev), (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "queries_to_f16") : CRS_OK;
+}
+
+int crs_scan_workspace_bytes(int nq, int dim, int k, int64_t n_rows, size_t* bytes) {
+  if (!bytes) return fail(CRS_EINVAL, "null pointer");
+  Plan p;
+  const int rc = make_plan(nq, dim, k, n_rows, &p);
+  if (rc) return rc;
+  *bytes = 2 * align_up(p.part_elems * 4, 256);
+  return CRS_OK;
+}
+
+static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const void* slab,
+                    const float* scales, int64_t n_rows, int k, void* ws, hipStream_t st,
+                    float** ps_out, int** pr_out) {
+  float* ps = reinterpret_cast<float*>(ws);
+  int* pr = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + align_up(p.part_elems * 4, 256));
+  crs::ScanArgs a;
+  a.q = reinterpret_cast<const _Float16*>(q16);
+  a.slab = slab;
+  a.scales = scales;
+  a.part_scores = ps;
+  a.part_rows = pr;
+  a.n_rows = (int)n_rows;
+  a.n_tiles = p.n_tiles;
+  a.nq = nq;
+  a.k = k;
+  const int e = (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
+                                           : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
+  *ps_out = ps;
+  *pr_out = pr;
+  return e;
+}
+
+int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,
+                    const float* scales_dev, int64_t n_rows, int k, int64_t id_base,
+                    void* workspace_dev, size_t workspace_bytes, float* out_scores_dev,
+                    int64_t* out_ids_dev, void* stream) {
+  Plan p;
+  int rc = make_plan(nq, dim, k, n_rows, &p);
+  if (rc) return rc;
+  if (!q16_dev || !slab_dev || !workspace_dev || !out_scores_dev || !out_ids_dev)
+    return fail(CRS_EINVAL, "null pointer");
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
+  if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
+  if (((uintptr_t)q16_dev | (uintptr_t)slab_dev) & 15) return fail(CRS_EINVAL, "q/slab must be 16-byte aligned");
+  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256)) return fail(CRS_ENOSPC, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* ps;
+  int* pr;
+  int e = run_scan(p, q16_dev, nq, slab_type, slab_dev, scales_dev, n_rows, k, workspace_dev, st, &ps, &pr);
+  if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
+  if (e) return hip_fail((hipError_t)e, "scan launch");
+  e = crs::merge_launch_i32(ps, pr, p.nwg, nq, k, k, id_base, out_scores_dev, out_ids_dev, st);
+  if (e) return hip_fail((hipError_t)e, "merge launch");
+  return CRS_OK;
+}
+
+int crs_merge_topk(const float* scores_dev, const int64_t* ids_dev, int nlists, int nq, int k_in,
+                   int k_out, float* out_scores_dev, int64_t* out_ids_dev, void* stream) {
+  if (nlists <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0) return fail(CRS_EINVAL, "bad sizes");
+  if (!scores_dev || !ids_dev || !out_scores_dev || !out_ids_dev) return fail(CRS_EINVAL, "null pointer");
+  const int e = crs::merge_launch_i64(scores_dev, ids_dev, nlists, nq, k_in, k_out, out_scores_dev,
+                                      out_ids_dev, (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "merge launch") : CRS_OK;
+}
+
+int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
+                    int64_t id_base, int k, float* scores_dev, int64_t* ids_dev, void* stream) {
+  if (nq <= 0 || dim <= 0 || k <= 0 || k > 64 || n_rows <= 0) return fail(CRS_EINVAL, "bad sizes (k <= 64)");
+  if (!q32_dev || !shadow_dev || !scores_dev || !ids_dev) return fail(CRS_EINVAL, "null pointer");
+  const int e = crs::rescore_launch(q32_dev, nq, dim, shadow_dev, n_rows, id_base, k, scores_dev,
+                                    ids_dev, (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "rescore launch") : CRS_OK;
+}
+
+int crs_time_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,
+                         const float* scales_dev, int64_t n_rows, int k, void* workspace_dev,
+                         size_t workspace_bytes, float* out_scores_dev, int64_t* out_ids_dev,
+                         void* stream, int iters, float* ms_total, float* ms_scan) {
+  Plan p;
+  int rc = make_plan(nq, dim, k, n_rows, &p);
+  if (rc) return rc;
+  if (iters <= 0 || !ms_total || !ms_scan) return fail(CRS_EINVAL, "bad iters / null outputs");
+  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256)) return fail(CRS_ENOSPC, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  hipError_t he;
+  if ((he = hipEventCreate(&e0)) != hipSuccess) return hip_fail(he, "hipEventCreate");
+  if ((he = hipEventCreate(&e1)) != hipSuccess) return hip_fail(he, "hipEventCreate");
+  float* ps;
+  int* pr;
+  // scan kernel alone
+  hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i) {
+    const int e = run_scan(p, q16_dev, nq, slab_type, slab_dev, scales_dev, n_rows, k, workspace_dev, st, &ps, &pr);
+    if (e) { hipEventDestroy(e0); hipEventDestroy(e1); return e == -1 ? fail(CRS_EINVAL, "unsupported padded dimension") : hip_fail((hipError_t)e, "scan launch"); }
+  }
+  hipEventRecord(e1, st);
+  if ((he = hipEventSynchronize(e1)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return hip_fail(he, "scan timing"); }
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  *ms_scan = ms / iters;
+  // scan + merge (what one crs_cosine_topk call costs on the device)
+  hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i) {
+    rc = crs_cosine_topk(q16_dev, nq, dim, slab_type, slab_dev, scales_dev, n_rows, k, 0, workspace_dev,
+                         workspace_bytes, out_scores_dev, out_ids_dev, stream);
+    if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
+  }
+  hipEventRecord(e1, st);
+  if ((he = hipEventSynchronize(e1)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return hip_fail(he, "total timing"); }
+  hipEventElapsedTime(&ms, e0, e1);
+  *ms_total = ms / iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return CRS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// convert.hip -- slab build / query conversion / exact re-score kernels (gfx950, HBM-bound).
+//
+//   slab_append : fp32 embeddings -> L2-normalised fp16 or int8(+scale) slab rows, optional fp32
+//                 shadow.  Replaces collection.add(embeddings=embeddings.tolist(), ...)
+//                 (reference rag/indexing.py:114-119): no Python lists, no sqlite, one pass.
+//   queries_to_f16 : the same normalise+cast for a query batch (rag/indexing.py:156-168 flatten
+//                 + ChromaDB's cosine-space normalisation).
+//   rescore     : exact fp32 <q, shadow[id]> for over-fetched candidates + per-row re-sort.
+//
+// One wave64 per row; rows are <= 1024 elements so a lane owns <= 16 strided elements.
+
+#include "scan.h"
+
+namespace crs {
+namespace {
+
+constexpr float kNegInf = -__builtin_huge_valf();
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  return x;
+}
+
+// grid: one wave per row, 4 waves per block
+template <bool I8>
+__global__ __launch_bounds__(256) void slab_append_kernel(const float* __restrict__ emb, int64_t n,
+                                                         int dim, int pdim, void* __restrict__ slab,
+                                                         float* __restrict__ scales,
+                                                         float* __restrict__ shadow, int64_t row0) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float* src = emb + r * dim;
+  float ss = 0.f;
+  for (int c = lane; c < dim; c += 64) {
+    const float x = src[c];
+    ss += x * x;
+  }
+  ss = wave_sum(ss);
+  const float inv_den = fmaxf(sqrtf(ss), 1e-12f);
+  const int64_t dr = row0 + r;
+  if (I8) {
+    float amax = 0.f;
+    for (int c = lane; c < dim; c += 64) amax = fmaxf(amax, fabsf(src[c] / inv_den));
+    amax = wave_max(amax);
+    const float sc = amax / 127.0f;
+    const float safe = sc > 0.f ? sc : 1.0f;
+    int8_t* dst = reinterpret_cast<int8_t*>(slab) + dr * pdim;
+    for (int c = lane; c < pdim; c += 64) {
+      float x = 0.f;
+      if (c < dim) x = src[c] / inv_den;
+      float qv = rintf(x / safe);
+      qv = fminf(fmaxf(qv, -127.f), 127.f);
+      dst[c] = (int8_t)qv;
+      if (shadow && c < dim) shadow[dr * dim + c] = x;
+    }
+    if (lane == 0) scales[dr] = sc;
+  } else {
+    _Float16* dst = reinterpret_cast<_Float16*>(slab) + dr * pdim;
+    for (int c = lane; c < pdim; c += 64) {
+      float x = 0.f;
+      if (c < dim) x = src[c] / inv_den;
+      dst[c] = (_Float16)x;
+      if (shadow && c < dim) shadow[dr * dim + c] = x;
+    }
+  }
+}
+
+// one wave per (query, slot)
+__global__ __launch_bounds__(256) void rescore_dot_kernel(const float* __restrict__ q32, int nq,
+                                                         int dim, const float* __restrict__ shadow,
+                                                         int64_t n_rows, int64_t id_base, int k,
+                                                         float* __restrict__ scores,
+                                                         const int64_t* __restrict__ ids) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= (int64_t)nq * k) return;
+  const int qi = (int)(e / k);
+  const int64_t id = ids[e];
+  if (id < 0) {
+    if (lane == 0) scores[e] = kNegInf;
+    return;
+  }
+  const int64_t row = id - id_base;
+  if (row < 0 || row >= n_rows) return;  // foreign shard: leave untouched
+  const float* a = q32 + (size_t)qi * dim;
+  const float* b = shadow + (size_t)row * dim;
+  float acc = 0.f;
+  for (int c = lane; c < dim; c += 64) acc = fmaf(a[c], b[c], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) scores[e] = acc;
+}
+
+// one wave per query, k <= 64: rank-by-counting sort on (score desc, id asc); empty slots last
+__global__ __launch_bounds__(64) void sort_rows_kernel(int nq, int k, float* __restrict__ scores,
+                                                      int64_t* __restrict__ ids) {
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x;
+  const bool in = lane < k;
+  float s = in ? scores[(size_t)qi * k + lane] : kNegInf;
+  int64_t id = in ? ids[(size_t)qi * k + lane] : -1;
+  if (id < 0) s = kNegInf;
+  int rank = 0;
+  for (int j = 0; j < k; ++j) {
+    const float sj = __shfl(s, j);
+    const int64_t ij = __shfl(id, j);
+    bool before;  // does entry j precede this lane's entry?
+    if (ij < 0) before = (id < 0) && (j < lane);
+    else if (id < 0) before = true;
+    else before = (sj > s) || (sj == s && ij < id);
+    rank += before ? 1 : 0;
+  }
+  if (in) {
+    scores[(size_t)qi * k + rank] = s;
+    ids[(size_t)qi * k + rank] = id;
+  }
+}
+
+}  // namespace
+
+int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_type, void* slab,
+                       float* scales, float* shadow, int64_t row0, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const unsigned blocks = (unsigned)((n + 3) / 4);
+  if (slab_type == 1)
+    hipLaunchKernelGGL((slab_append_kernel<true>), dim3(blocks), dim3(256), 0, stream, emb, n, dim,
+                       pdim, slab, scales, shadow, row0);
+  else
+    hipLaunchKernelGGL((slab_append_kernel<false>), dim3(blocks), dim3(256), 0, stream, emb, n, dim,
+                       pdim, slab, scales, shadow, row0);
+  return (int)hipGetLastError();
+}
+
+int queries_to_f16_launch(const float* q, int nq, int dim, int pdim, _Float16* out,
+                          hipStream_t stream) {
+  return slab_append_launch(q, nq, dim, pdim, 0, out, nullptr, nullptr, 0, stream);
+}
+
+int rescore_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows,
+                   int64_t id_base, int k, float* scores, int64_t* ids, hipStream_t stream) {
+  const int64_t e = (int64_t)nq * k;
+  if (e <= 0) return 0;
+  hipLaunchKernelGGL(rescore_dot_kernel, dim3((unsigned)((e + 3) / 4)), dim3(256), 0, stream, q32,
+                     nq, dim, shadow, n_rows, id_base, k, scores, ids);
+  hipLaunchKernelGGL(sort_rows_kernel, dim3(nq), dim3(64), 0, stream, nq, k, scores, ids);
+  return (int)hipGetLastError();
+}
+
+}  // namespace crs

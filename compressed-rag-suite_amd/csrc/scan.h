@@ -1,0 +1,38 @@
+// Internal (C++) declarations shared by the HIP translation units of libcrs_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crs {
+
+struct ScanArgs {
+  const _Float16* q;      // [nq, D] fp16, zero padded to D
+  const void* slab;       // [n_rows, D] fp16 (or int8)
+  const float* scales;    // int8 slabs: one fp32 per row, else nullptr
+  float* part_scores;     // [nwg, nq, k]
+  int* part_rows;         // [nwg, nq, k] local row index, -1 = empty
+  int n_rows;
+  int n_tiles;
+  int nq;
+  int k;
+};
+
+int scan_tile_rows(int pdim);
+// returns hipError_t as int, -1 for an unsupported padded dimension
+int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
+int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
+
+// merge.hip
+int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,
+                     int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream);
+int merge_launch_i64(const float* scores, const int64_t* ids, int nlists, int nq, int k_in, int k_out,
+                     float* out_scores, int64_t* out_ids, hipStream_t stream);
+
+// convert.hip
+int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_type, void* slab,
+                       float* scales, float* shadow, int64_t row0, hipStream_t stream);
+int queries_to_f16_launch(const float* q, int nq, int dim, int pdim, _Float16* out, hipStream_t stream);
+int rescore_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows,
+                   int64_t id_base, int k, float* scores, int64_t* ids, hipStream_t stream);
+
+}  // namespace crs

@@ -1,0 +1,407 @@
+// scan.hip -- K9: exact cosine scan + in-kernel top-k over an HBM-resident vector slab (gfx950).
+//
+// Replaces the arithmetic behind collection.query() (reference rag/indexing.py:171-176; ChromaDB's
+// HNSW walk) with a brute-force, exact, bandwidth-bound pass:
+//
+//   scores[q, r] = <Q[q, :], slab[r, :]>          (unit rows  =>  cosine)
+//   per query keep the k best by (score desc, row asc)
+//
+// Structure (one workgroup = 4 wave64):
+//   * the slab is streamed ONCE, in tiles of TR whole rows (a tile is one contiguous
+//     TR*D*sizeof(elem) block of HBM, read with 16-byte-per-lane coalesced loads), staged through
+//     LDS with an XOR swizzle so the MFMA A-fragment ds_read_b128 is bank-conflict free;
+//   * each wave keeps the fragments of ITS 16 queries (full depth D) in VGPRs for the whole kernel,
+//     so queries never touch LDS; all four waves read the same slab tile from LDS;
+//   * v_mfma_f32_16x16x32_f16 with A = slab rows, B = queries: lane l ends up holding the scores
+//     of query (l & 15) for rows 4*(l >> 4) .. +3 of the 16-row sub-tile;
+//   * top-k: every lane filters its scores against a per-query running threshold tau and appends
+//     survivors to a private LDS list (no atomics).  When a list is nearly full the wave compacts:
+//     register sorting networks + two cross-lane bitonic merges give the exact k-th best of the
+//     query's candidates, which becomes the new tau; survivors are spread back evenly.
+//     Rows are visited in ascending order, so a later row that merely ties tau can never displace
+//     an earlier one: the strict compare implements the (score desc, row asc) rule exactly.
+//   * each wave finally writes <= k (score, row) pairs per query; merge.hip reduces the per-workgroup
+//     lists to the final sorted top-k.
+//
+// HBM-bound by design: algorithmic bytes per launch = n_rows * D * sizeof(elem).
+
+#include "scan.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crs {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// ---------------------------------------------------------------- register sorting networks
+template <int L>
+__device__ __forceinline__ void bitonic_sort_desc(float (&v)[L]) {
+#pragma unroll
+  for (int k = 2; k <= L; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool desc = ((i & k) == 0);
+          const float a = v[i], b = v[l];
+          const float hi = fmaxf(a, b), lo = fminf(a, b);
+          v[i] = desc ? hi : lo;
+          v[l] = desc ? lo : hi;
+        }
+      }
+    }
+  }
+}
+
+// v is bitonic -> sorted descending
+template <int L>
+__device__ __forceinline__ void bitonic_clean_desc(float (&v)[L]) {
+#pragma unroll
+  for (int j = L >> 1; j > 0; j >>= 1) {
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const int l = i ^ j;
+      if (l > i) {
+        const float a = v[i], b = v[l];
+        v[i] = fmaxf(a, b);
+        v[l] = fminf(a, b);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ int quad_sum(int x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+__device__ __forceinline__ int quad_min(int x) {
+  x = min(x, __shfl_xor(x, 16));
+  x = min(x, __shfl_xor(x, 32));
+  return x;
+}
+
+// m is sorted descending: m[idx] = min over j <= idx (written as a min chain so the compiler keeps
+// the array in registers instead of indexing it through scratch)
+template <int L>
+__device__ __forceinline__ float pick(const float (&m)[L], int idx) {
+  float t = m[0];
+#pragma unroll
+  for (int j = 1; j < L; ++j) t = fminf(t, (j <= idx) ? m[j] : __builtin_huge_valf());
+  return t;
+}
+
+// The k-th best (1-based k) score among the 4*L candidates of this lane's query, L = 16, k <= 16.
+// `s` = this lane's L scores (unsorted, -inf padded); destroyed.
+__device__ __forceinline__ float kth_of_quad(float (&s)[16], int k) {
+  bitonic_sort_desc<16>(s);
+  float m[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) m[j] = fmaxf(s[j], __shfl_xor(s[15 - j], 16));
+  bitonic_clean_desc<16>(m);  // top-16 of the lane pair, both partners hold the same list
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s[j] = fmaxf(m[j], __shfl_xor(m[15 - j], 32));
+  bitonic_clean_desc<16>(s);  // top-16 of the quad
+  return pick<16>(s, k - 1);
+}
+
+// L = 32, k <= 64: the sorted top-64 of the quad's 128 candidates lives in a lane PAIR
+// (lane g=0/2 holds ranks 0..31, lane g=1/3 ranks 32..63).
+__device__ __forceinline__ float kth_of_quad(float (&s)[32], int k) {
+  const int lane = threadIdx.x & 63;
+  const bool upper = (lane >> 4) & 1;  // g odd: holds the lower-ranked half of its pair
+  bitonic_sort_desc<32>(s);
+  float m[32];
+  // full merge inside the pair (g, g^1): lower g keeps the 32 largest, upper the 32 smallest
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float o = __shfl_xor(s[31 - j], 16);
+    m[j] = upper ? fminf(s[j], o) : fmaxf(s[j], o);
+  }
+  bitonic_clean_desc<32>(m);  // pair now holds 64 sorted: [lower lane | upper lane]
+  // top-64 of the two pairs: element i of this pair against element 63-i of the other pair,
+  // which sits in lane^48 at index 31-j.
+#pragma unroll
+  for (int j = 0; j < 32; ++j) s[j] = fmaxf(m[j], __shfl_xor(m[31 - j], 48));
+  // (lower | upper) is a bitonic sequence of 64: first the distance-32 exchange across the pair
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float o = __shfl_xor(s[j], 16);
+    m[j] = upper ? fminf(s[j], o) : fmaxf(s[j], o);
+  }
+  bitonic_clean_desc<32>(m);
+  const float t = pick<32>(m, (k - 1) & 31);
+  // rank k-1 sits in pair-lane ((k-1) >> 5)
+  const int src = (lane & 47 & ~16) | (((k - 1) >> 5) << 4);
+  return __shfl(t, src);
+}
+
+// ---------------------------------------------------------------- per-wave candidate lists
+// sbuf/ibuf: [L][64] (slot-major, lane-minor => conflict-free 4-byte accesses).
+// On exit (not FINAL) every query keeps exactly min(k, total) candidates, spread round-robin over
+// its 4 lanes, and tau is the k-th best seen so far.  FINAL writes them to out_s/out_i instead
+// (k slots per query, unused slots get (-inf, -1)); out pointers are per-lane (this lane's query).
+template <int L, bool FINAL>
+__device__ __forceinline__ void compact(float* __restrict__ sbuf, int* __restrict__ ibuf, int lane,
+                                        int& cnt, float& tau, int k, float* out_s, int* out_i,
+                                        bool q_valid) {
+  float v[L], s[L];
+  int id[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    const bool in = j < cnt;
+    const float x = sbuf[j * 64 + lane];
+    v[j] = in ? x : kNegInf;
+    s[j] = v[j];
+    id[j] = ibuf[j * 64 + lane];
+  }
+  const int total = quad_sum(cnt);
+  float tnew = kth_of_quad(s, k);  // -inf when total < k (padding)
+  int n_gt = 0, n_eq = 0;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    n_gt += (j < cnt && v[j] > tnew) ? 1 : 0;
+    n_eq += (j < cnt && v[j] == tnew) ? 1 : 0;
+  }
+  n_gt = quad_sum(n_gt);
+  n_eq = quad_sum(n_eq);
+  // ties on the threshold score: keep only the `need` smallest rows among the equal ones
+  int need = (total >= k) ? (k - n_gt) : n_eq;
+  int idthr = 0x7fffffff;
+  if (__any(n_eq > need)) {
+    int thr = -1;
+    const int rounds = (n_eq > need) ? need : 0;
+    for (int it = 0; __any(it < rounds); ++it) {
+      int c = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < L; ++j)
+        if (j < cnt && v[j] == tnew && id[j] > thr) c = min(c, id[j]);
+      c = quad_min(c);
+      if (it < rounds) thr = c;
+    }
+    if (n_eq > need) idthr = thr;
+  }
+  unsigned km = 0;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    const bool keep = (j < cnt) && (v[j] > tnew || (v[j] == tnew && id[j] <= idthr));
+    km |= (keep ? 1u : 0u) << j;
+  }
+  const int c = __popc(km);
+  const int qb = lane & 15;
+  const int c0 = __shfl(c, qb), c1 = __shfl(c, qb + 16), c2 = __shfl(c, qb + 32),
+            c3 = __shfl(c, qb + 48);
+  const int g = lane >> 4;
+  const int prefix = (g > 0 ? c0 : 0) + (g > 1 ? c1 : 0) + (g > 2 ? c2 : 0);
+  const int kept = c0 + c1 + c2 + c3;
+  if (FINAL) {
+    if (q_valid) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        if ((km >> j) & 1u) {
+          const int p = prefix + __popc(km & ((1u << j) - 1u));
+          out_s[p] = v[j];
+          out_i[p] = id[j];
+        }
+      }
+      for (int p = kept + g; p < k; p += 4) {
+        out_s[p] = kNegInf;
+        out_i[p] = -1;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      if ((km >> j) & 1u) {
+        const int p = prefix + __popc(km & ((1u << j) - 1u));
+        const int dl = qb + ((p & 3) << 4);
+        sbuf[(p >> 2) * 64 + dl] = v[j];
+        ibuf[(p >> 2) * 64 + dl] = id[j];
+      }
+    }
+    cnt = (kept - g + 3) >> 2;
+    if (total >= k) tau = tnew;
+  }
+}
+
+// ---------------------------------------------------------------- the scan kernel
+template <int D, int TR, int L>
+struct Cfg {
+  static constexpr int kCpr = D / 8;                       // 16-byte chunks per row
+  static constexpr int kTileBytes = TR * D * 2;            // fp16
+  static constexpr int kLoads = kTileBytes / (kThreads * 16);
+  static constexpr int kKsteps = D / 32;
+  static constexpr int kRt = TR / 16;
+  static constexpr int kListBytes = kWaves * L * 64 * 4;   // per array (scores / rows)
+  static constexpr int kLds = 2 * kTileBytes + 2 * kListBytes;
+  static_assert(D % 128 == 0, "row length must be a multiple of 128 elements");
+  static_assert(TR % 16 == 0, "tile rows must be a multiple of 16");
+  static_assert(kTileBytes % (kThreads * 16) == 0, "tile must split into whole 16-byte loads");
+};
+
+template <int D, int TR, int L>
+__global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a) {
+  using C = Cfg<D, TR, L>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile_buf = smem;
+  float* sbuf_all = reinterpret_cast<float*>(smem + 2 * C::kTileBytes);
+  int* ibuf_all = reinterpret_cast<int*>(smem + 2 * C::kTileBytes + C::kListBytes);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lr = lane & 15;  // A: row inside the 16-row sub-tile; B/D: query inside the wave's 16
+  const int kq = lane >> 4;  // A/B: which 8-element k-quarter; D: which group of 4 rows
+  float* sbuf = sbuf_all + wave * (L * 64);
+  int* ibuf = ibuf_all + wave * (L * 64);
+
+  const int nwg = gridDim.x;
+  const int qi = blockIdx.y * 64 + wave * 16 + lr;
+  const bool q_valid = qi < a.nq;
+  const bool wave_active = (blockIdx.y * 64 + wave * 16) < a.nq;  // wave-uniform
+
+  // ---- this wave's query fragments, resident in VGPRs for the whole kernel
+  f16x8 qf[C::kKsteps];
+  {
+    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 32) : z;
+    }
+  }
+
+  // ---- staging geometry: load j of this thread covers 16-byte chunk P = j*256 + tid of the tile
+  int lds_dst[C::kLoads];
+#pragma unroll
+  for (int j = 0; j < C::kLoads; ++j) {
+    const int P = j * kThreads + tid;
+    const int r = P / C::kCpr, c = P % C::kCpr;
+    lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+  }
+  // A-fragment read offsets for (ks & 3) = 0..3 (row lr, chunk ks*4 + kq, swizzled by row)
+  int a_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
+
+  const char* slab = reinterpret_cast<const char*>(a.slab);
+  const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
+
+  float tau = q_valid ? kNegInf : __builtin_huge_valf();
+  int cnt = 0;
+
+  uint4 st[C::kLoads];
+  int t = blockIdx.x;
+  if (t < a.n_tiles) {
+#pragma unroll
+    for (int j = 0; j < C::kLoads; ++j) {
+      size_t off = (size_t)t * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
+      off = off > last_chunk ? last_chunk : off;
+      st[j] = *reinterpret_cast<const uint4*>(slab + off);
+    }
+#pragma unroll
+    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<uint4*>(tile_buf + lds_dst[j]) = st[j];
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (; t < a.n_tiles; t += nwg) {
+    // issue the next tile's loads now, park them in LDS after this tile's math (past the
+    // last tile the clamp turns them into harmless re-reads of the slab's final 16 bytes)
+    const int tn = t + nwg;
+#pragma unroll
+    for (int j = 0; j < C::kLoads; ++j) {
+      size_t off = (size_t)tn * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
+      off = off > last_chunk ? last_chunk : off;
+      st[j] = *reinterpret_cast<const uint4*>(slab + off);
+    }
+    if (wave_active) {
+      const char* buf = tile_buf + cur * C::kTileBytes;
+#pragma unroll
+      for (int rt = 0; rt < C::kRt; ++rt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::kKsteps; ++ks) {
+          const f16x8 af = *reinterpret_cast<const f16x8*>(
+              buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
+        }
+        const int row0 = t * TR + rt * 16 + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sc = acc[i];
+          const int row = row0 + i;
+          if (sc > tau && row < a.n_rows) {
+            sbuf[cnt * 64 + lane] = sc;
+            ibuf[cnt * 64 + lane] = row;
+            ++cnt;
+          }
+        }
+        if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid);
+      }
+    }
+    {
+      char* nb = tile_buf + (cur ^ 1) * C::kTileBytes;
+#pragma unroll
+      for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<uint4*>(nb + lds_dst[j]) = st[j];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if (wave_active) {
+    const size_t o = ((size_t)blockIdx.x * a.nq + (q_valid ? qi : 0)) * a.k;
+    compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
+  }
+}
+
+template <int D, int TR, int L>
+int launch_cfg(const ScanArgs& a, int nwg, hipStream_t stream) {
+  using C = Cfg<D, TR, L>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_f16_kernel<D, TR, L>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid(nwg, (a.nq + 63) / 64);
+  hipLaunchKernelGGL((scan_f16_kernel<D, TR, L>), grid, dim3(kThreads), C::kLds, stream, a);
+  return (int)hipGetLastError();
+}
+
+template <int D, int TR>
+int launch_d(const ScanArgs& a, int nwg, hipStream_t stream) {
+  if (a.k <= 16) return launch_cfg<D, TR, 16>(a, nwg, stream);
+  return launch_cfg<D, TR, 32>(a, nwg, stream);
+}
+
+}  // namespace
+
+int scan_tile_rows(int pdim) { return pdim <= 512 ? 32 : 16; }
+
+int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream) {
+  switch (pdim) {
+    case 128: return launch_d<128, 32>(a, nwg, stream);
+    case 256: return launch_d<256, 32>(a, nwg, stream);
+    case 384: return launch_d<384, 32>(a, nwg, stream);
+    case 512: return launch_d<512, 32>(a, nwg, stream);
+    case 640: return launch_d<640, 16>(a, nwg, stream);
+    case 768: return launch_d<768, 16>(a, nwg, stream);
+    case 896: return launch_d<896, 16>(a, nwg, stream);
+    case 1024: return launch_d<1024, 16>(a, nwg, stream);
+    default: return -1;
+  }
+}
+
+}  // namespace crs

@@ -1,0 +1,172 @@
+"""ctypes binding of libcrs_hip.so (the C ABI in include/crs_hip.h).
+
+PyTorch is used only as plumbing: device memory (``tensor.data_ptr()``), the current HIP stream
+and ``torch.distributed``.  There is no CPU fallback anywhere in this module: if the shared
+library is missing, or there is no GPU, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER, byref
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcrs_hip.so")
+
+SLAB_F16 = 0
+SLAB_I8 = 1
+MAX_K = 64
+
+# name -> (restype, argtypes); mirrors include/crs_hip.h one to one
+_SIGNATURES = {
+    "crs_last_error": (c_char_p, []),
+    "crs_abi_version": (c_int, []),
+    "crs_padded_dim": (c_int, [c_int]),
+    "crs_slab_append_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_int64, c_void_p]),
+    "crs_queries_to_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "crs_scan_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_size_t)]),
+    "crs_cosine_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int,
+                                c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "crs_merge_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p]),
+    "crs_rescore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p,
+                                c_void_p, c_void_p]),
+    "crs_time_cosine_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
+                                     c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
+                                     POINTER(c_float), POINTER(c_float)]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    """A libcrs_hip.so call failed (the message comes from crs_last_error())."""
+
+
+def register_signatures(table: dict) -> None:
+    """Let sibling modules (the encoder binding) add their entry points before load()."""
+    _SIGNATURES.update(table)
+    if _lib is not None:
+        for name, (res, args) in table.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {os.path.dirname(LIB_PATH)}` -- this path has no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().crs_last_error()
+        raise NativeError(f"libcrs_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def padded_dim(dim: int) -> int:
+    return int(load().crs_padded_dim(int(dim)))
+
+
+def _stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise NativeError("no ROCm GPU visible: the MI355X vector store has no CPU fallback")
+
+
+# ----------------------------------------------------------------------------- wrappers
+def slab_append_f32(emb, slab, row0: int, slab_type: int, scales=None, shadow=None) -> None:
+    """emb: cuda fp32 [n, dim]; slab: cuda fp16/int8 [cap, pdim]; writes rows row0..row0+n."""
+    n, dim = emb.shape
+    check(load().crs_slab_append_f32(_ptr(emb), n, dim, slab_type, _ptr(slab), _ptr(scales),
+                                     _ptr(shadow), row0, _stream_ptr()))
+
+
+def queries_to_f16(q32):
+    import torch
+    nq, dim = q32.shape
+    out = torch.empty((nq, padded_dim(dim)), dtype=torch.float16, device=q32.device)
+    check(load().crs_queries_to_f16(_ptr(q32), nq, dim, _ptr(out), _stream_ptr()))
+    return out
+
+
+def scan_workspace_bytes(nq: int, dim: int, k: int, n_rows: int) -> int:
+    out = c_size_t(0)
+    check(load().crs_scan_workspace_bytes(nq, dim, k, n_rows, byref(out)))
+    return int(out.value)
+
+
+def cosine_topk(q16, slab, n_rows: int, dim: int, k: int, *, slab_type: int = SLAB_F16, scales=None,
+                id_base: int = 0, workspace=None, out_scores=None, out_ids=None):
+    """q16: cuda fp16 [nq, pdim]; slab: cuda [>= n_rows, pdim]. Returns (scores fp32, ids int64) [nq, k]."""
+    import torch
+    nq = q16.shape[0]
+    need = scan_workspace_bytes(nq, dim, k, n_rows)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=q16.device)
+    if out_scores is None:
+        out_scores = torch.empty((nq, k), dtype=torch.float32, device=q16.device)
+    if out_ids is None:
+        out_ids = torch.empty((nq, k), dtype=torch.int64, device=q16.device)
+    check(load().crs_cosine_topk(_ptr(q16), nq, dim, slab_type, _ptr(slab), _ptr(scales), n_rows, k,
+                                 id_base, _ptr(workspace), workspace.numel(), _ptr(out_scores),
+                                 _ptr(out_ids), _stream_ptr()))
+    return out_scores, out_ids
+
+
+def merge_topk(scores, ids, k_out: int):
+    """scores/ids: cuda [G, nq, k_in] (fp32 / int64) -> global top-k_out per query."""
+    import torch
+    g, nq, k_in = scores.shape
+    out_s = torch.empty((nq, k_out), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
+    check(load().crs_merge_topk(_ptr(scores), _ptr(ids), g, nq, k_in, k_out, _ptr(out_s), _ptr(out_i),
+                                _stream_ptr()))
+    return out_s, out_i
+
+
+def rescore_f32(q32, shadow, n_rows: int, id_base: int, scores, ids) -> None:
+    nq, dim = q32.shape
+    k = scores.shape[1]
+    check(load().crs_rescore_f32(_ptr(q32), nq, dim, _ptr(shadow), n_rows, id_base, k, _ptr(scores),
+                                 _ptr(ids), _stream_ptr()))
+
+
+def time_cosine_topk(q16, slab, n_rows: int, dim: int, k: int, iters: int, *, slab_type: int = SLAB_F16,
+                     scales=None):
+    """hipEvent-timed launches on the current stream: returns (ms per scan+merge, ms per scan kernel)."""
+    import torch
+    nq = q16.shape[0]
+    need = scan_workspace_bytes(nq, dim, k, n_rows)
+    ws = torch.empty(need, dtype=torch.uint8, device=q16.device)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=q16.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=q16.device)
+    ms_total, ms_scan = c_float(0), c_float(0)
+    check(load().crs_time_cosine_topk(_ptr(q16), nq, dim, slab_type, _ptr(slab), _ptr(scales), n_rows, k,
+                                      _ptr(ws), ws.numel(), _ptr(out_s), _ptr(out_i), _stream_ptr(),
+                                      iters, byref(ms_total), byref(ms_scan)))
+    return float(ms_total.value), float(ms_scan.value)

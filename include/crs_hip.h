@@ -1,0 +1,92 @@
+/* crs_hip.h -- C ABI of libcrs_hip.so: the MI355X (gfx950) embed -> index -> retrieve hot path.
+ *
+ * The reference (zahraamselim/compressed-rag-suite) is pure Python; the arithmetic of this path
+ * lives in third-party wheels it calls (sentence-transformers / ChromaDB).  Each entry point
+ * below names the reference call site it replaces.  All pointers marked "dev" are device (HBM)
+ * addresses; no torch types cross this boundary.  `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Every function returns 0 on success or a negative CRS_E* code;
+ * crs_last_error() returns a thread-local message for the last failure.
+ *
+ * Nothing here ever falls back to the CPU: a missing GPU is an error.
+ */
+#ifndef CRS_HIP_H
+#define CRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRS_OK 0
+#define CRS_EINVAL (-1)   /* bad argument (shape, alignment, k out of range) */
+#define CRS_ENOSPC (-2)   /* workspace too small */
+#define CRS_EHIP (-3)     /* HIP runtime error (message has hipGetErrorString) */
+
+#define CRS_MAX_K 64      /* largest k one scan launch selects exactly */
+
+/* Slab element types (the vector store's row format in HBM). */
+#define CRS_SLAB_F16 0    /* fp16 unit rows                                   */
+#define CRS_SLAB_I8 1     /* int8 rows + one fp32 scale per row (s = max|x|/127) */
+
+const char* crs_last_error(void);
+int crs_abi_version(void);
+
+/* Rows of the slab are padded to a multiple of 128 elements (zeros); this returns that padded
+ * dimension for an embedding dimension `dim` (384 -> 384, 768 -> 768, 100 -> 128). */
+int crs_padded_dim(int dim);
+
+/* ---- index build: replaces collection.add(embeddings=...) -- rag/indexing.py:114-119 ------
+ * Converts `n` fp32 embedding rows (dev, row stride `dim`) into slab rows starting at row
+ * `row0` of `slab` (dev, row stride crs_padded_dim(dim) elements).  Rows are L2-normalised in
+ * fp32 first (x / max(||x||, 1e-12)): ChromaDB's cosine space does the same, and it is the
+ * identity on already-normalised encoder output (rag/embedding.py:69).  For CRS_SLAB_I8,
+ * `scales` (dev fp32, one per slab row) receives max|x|/127 of the normalised row.
+ * `shadow_f32` (dev, stride `dim`, may be NULL) receives the normalised fp32 rows for exact
+ * re-scoring. */
+int crs_slab_append_f32(const float* emb_dev, int64_t n, int dim, int slab_type, void* slab_dev,
+                        float* scales_dev, float* shadow_f32_dev, int64_t row0, void* stream);
+
+/* Query side of the same conversion: fp32 [nq, dim] -> normalised fp16 [nq, crs_padded_dim(dim)]. */
+int crs_queries_to_f16(const float* q_dev, int nq, int dim, void* q16_dev, void* stream);
+
+/* ---- search: replaces collection.query(query_embeddings, n_results) -- rag/indexing.py:171-176
+ * Exact cosine top-k of `nq` fp16 queries against `n_rows` slab rows on the current device.
+ *   q16_dev   fp16 [nq, pdim]  (pdim = crs_padded_dim(dim)), unit rows, zero padded
+ *   slab_dev  fp16 or int8 [n_rows, pdim]; scales_dev fp32 [n_rows] for CRS_SLAB_I8 else NULL
+ *   k         1..CRS_MAX_K; if k > n_rows the tail slots are (-inf, -1)
+ *   id_base   added to row indices (the shard's first global row)
+ *   out_scores fp32 [nq, k] cosine, descending; out_ids int64 [nq, k]; ties -> lower id first
+ * Workspace: crs_scan_workspace_bytes() bytes of device memory, contents don't-care. */
+int crs_scan_workspace_bytes(int nq, int dim, int k, int64_t n_rows, size_t* bytes);
+int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,
+                    const float* scales_dev, int64_t n_rows, int k, int64_t id_base,
+                    void* workspace_dev, size_t workspace_bytes, float* out_scores_dev,
+                    int64_t* out_ids_dev, void* stream);
+
+/* ---- multi-shard merge (new: the reference is single process) ------------------------------
+ * Merges `nlists` partial results laid out [nlists, nq, k_in] (what an RCCL all-gather of the
+ * per-shard crs_cosine_topk outputs delivers) into the global top-k_out per query; slots with
+ * id < 0 are ignored.  Same ordering rule. */
+int crs_merge_topk(const float* scores_dev, const int64_t* ids_dev, int nlists, int nq, int k_in,
+                   int k_out, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* Exact fp32 re-score of candidates: out[i, j] = <q32[i, :], shadow[ids[i, j], :]> for ids >= 0
+ * (id_base subtracted first), then each row re-sorted by (score desc, id asc). Used when the
+ * store keeps an fp32 shadow and over-fetches (recall vs an exact fp32 ranking). */
+int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
+                    int64_t id_base, int k, float* scores_dev, int64_t* ids_dev, void* stream);
+
+/* Timing hook for bench.py: runs `iters` back-to-back crs_cosine_topk launches bracketed by
+ * hipEvents on `stream` and returns the mean milliseconds of ONE launch pair (scan + merge)
+ * in *ms_total and of the scan kernel alone in *ms_scan. */
+int crs_time_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,
+                         const float* scales_dev, int64_t n_rows, int k, void* workspace_dev,
+                         size_t workspace_bytes, float* out_scores_dev, int64_t* out_ids_dev,
+                         void* stream, int iters, float* ms_total, float* ms_scan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRS_HIP_H */
