@@ -33,7 +33,6 @@ int device_cus() {
   return cus[dev];
 }
 
-constexpr int kWgPerCu = 2;
 
 struct Plan {
   int pdim, tile_rows, n_tiles, nwg;
@@ -49,7 +48,7 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, Plan* p) {
   p->pdim = crs_padded_dim(dim);
   p->tile_rows = crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
-  const int cap = cus * kWgPerCu;
+  const int cap = cus * crs::scan_wg_per_cu();
   p->nwg = p->n_tiles < cap ? p->n_tiles : cap;
   p->part_elems = (size_t)p->nwg * nq * k;
   return CRS_OK;
@@ -143,7 +142,7 @@ int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const v
 
 int crs_merge_topk(const float* scores_dev, const int64_t* ids_dev, int nlists, int nq, int k_in,
                    int k_out, float* out_scores_dev, int64_t* out_ids_dev, void* stream) {
-  if (nlists <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0) return fail(CRS_EINVAL, "bad sizes");
+  if (nlists <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0 || k_out > CRS_MAX_K) return fail(CRS_EINVAL, "bad sizes (k_out <= CRS_MAX_K)");
   if (!scores_dev || !ids_dev || !out_scores_dev || !out_ids_dev) return fail(CRS_EINVAL, "null pointer");
   const int e = crs::merge_launch_i64(scores_dev, ids_dev, nlists, nq, k_in, k_out, out_scores_dev,
                                       out_ids_dev, (hipStream_t)stream);

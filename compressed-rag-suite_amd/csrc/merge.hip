@@ -2,14 +2,19 @@
 //
 // Two users, one kernel:
 //   * stage 2 of crs_cosine_topk: the per-workgroup lists scan.hip leaves behind
-//     ([nwg, nq, k] fp32 score + int32 local row);
+//     ([nq, nwg, k] fp32 score + int32 local row);
 //   * crs_merge_topk: the per-shard results an RCCL all-gather delivers ([G, nq, k] fp32 + int64
 //     global id) -- K10 of SURVEY.md section 2.3, new relative to the single-process reference.
 //
-// One 256-thread workgroup per query.  All keys (score, id) are distinct, so the result is
-// produced by k_out rounds of "largest key strictly below the previous winner": every thread
-// scans its strided share of the (L2-resident, KiB-sized) candidate set, a wave64 shuffle
-// reduction and one LDS exchange pick the round's winner.  Order: score descending, id ascending.
+// One 256-thread workgroup per query, m = nlists * k_in candidates (L2-resident, KiB-sized):
+//   1. every thread streams its strided share and keeps its best score ("bucket maximum");
+//   2. the k-th largest of the 256 bucket maxima is a lower bound tau on the true k-th best
+//      (those k maxima are k distinct candidates).  It is found without atomics: a 64-lane
+//      bitonic sort per wave (shuffles), then three "top-64 of two sorted lists" merges via LDS;
+//   3. candidates with score >= tau (typically k .. 2k of them) are appended to an LDS list;
+//   4. each candidate's rank among the list = its output slot (order: score desc, id asc).
+// If the list overflows (only when thousands of candidates tie), the kernel falls back to
+// k_out rounds of workgroup-wide arg-max, which is slow but exact for any input.
 
 #include "scan.h"
 
@@ -17,102 +22,175 @@ namespace crs {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kCap = 1024;  // LDS candidate list capacity
 constexpr float kNegInf = -__builtin_huge_valf();
-
-template <typename IdT>
-struct Key {
-  float s;
-  IdT id;
-};
 
 template <typename IdT>
 __device__ __forceinline__ bool better(float s, IdT id, float s2, IdT id2) {
   return s > s2 || (s == s2 && id < id2);
 }
 
+// full bitonic sort (descending by lane) of one value per lane across a wave64
+__device__ __forceinline__ float wave_sort_desc(float v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float o = __shfl_xor(v, j);
+      const bool lower = (lane & j) == 0;
+      const bool desc = (lane & k) == 0;       // k == 64: always descending
+      const bool want_max = (lower == desc);
+      v = want_max ? fmaxf(v, o) : fminf(v, o);
+    }
+  }
+  return v;
+}
+// v is a bitonic sequence across the wave -> sorted descending
+__device__ __forceinline__ float wave_clean_desc(float v, int lane) {
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) {
+    const float o = __shfl_xor(v, j);
+    v = ((lane & j) == 0) ? fmaxf(v, o) : fminf(v, o);
+  }
+  return v;
+}
+
 template <typename IdT>
 __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict__ scores,
                                                         const IdT* __restrict__ ids, int nlists,
-                                                        int nq, int k_in, int k_out,
-                                                        int64_t id_base, float* __restrict__ out_s,
+                                                        int k_in, int k_out, size_t list_stride,
+                                                        size_t q_stride, int64_t id_base,
+                                                        float* __restrict__ out_s,
                                                         int64_t* __restrict__ out_i) {
-  __shared__ float sh_s[2][4];
-  __shared__ IdT sh_i[2][4];
+  __shared__ float sh_sorted[4][64];
+  __shared__ float sh_cs[kCap];
+  __shared__ IdT sh_ci[kCap];
+  __shared__ int sh_cnt;
+  __shared__ float sh_rs[2][4];
+  __shared__ IdT sh_ri[2][4];
+
   const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = nlists * k_in;
-  const IdT kWorstId = (IdT)0x7fffffff;  // only compared against when s == -inf
+  // candidate e = (list e / k_in, slot e % k_in) lives at list*list_stride + q*q_stride + slot
+  // (== e when a query's lists are contiguous).  Threads walk e = tid, tid+256, ... eight at a
+  // time with all loads issued before any use, so L2 latency is paid once per batch of 8.
+  const float* qs = scores + (size_t)q * q_stride;
+  const IdT* qi = ids + (size_t)q * q_stride;
+  const bool contig = (list_stride == (size_t)k_in);
+#define CRS_FOR_EACH_ENTRY(BODY)                                                         \
+  for (int e0 = tid; e0 < m; e0 += 8 * kThreads) {                                       \
+    float s_[8];                                                                         \
+    IdT id_[8];                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
+      const int e = e0 + u * kThreads;                                                   \
+      const bool in = e < m;                                                             \
+      size_t at = 0;                                                                     \
+      if (in) at = contig ? (size_t)e : (size_t)(e / k_in) * list_stride + (e % k_in);   \
+      s_[u] = qs[at];                                                                    \
+      id_[u] = in ? qi[at] : (IdT)-1;                                                    \
+    }                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
+      const float s = s_[u];                                                             \
+      const IdT id = id_[u];                                                             \
+      BODY;                                                                              \
+    }                                                                                    \
+  }
+  float* os = out_s + (size_t)q * k_out;
+  int64_t* oi = out_i + (size_t)q * k_out;
 
+  if (tid == 0) sh_cnt = 0;
+  for (int r = tid; r < k_out; r += kThreads) { os[r] = kNegInf; oi[r] = -1; }
+
+  // 1. bucket maxima
+  float best = kNegInf;
+  CRS_FOR_EACH_ENTRY({ best = fmaxf(best, (id >= 0) ? s : kNegInf); })
+  // 2. k-th largest of the 256 maxima (k_out <= 64)
+  const float sorted = wave_sort_desc(best, lane);
+  sh_sorted[wave][lane] = sorted;
+  __syncthreads();
+  float a = fmaxf(sh_sorted[0][lane], sh_sorted[1][63 - lane]);
+  float b = fmaxf(sh_sorted[2][lane], sh_sorted[3][63 - lane]);
+  a = wave_clean_desc(a, lane);
+  b = wave_clean_desc(b, lane);
+  float t = fmaxf(a, __shfl(b, 63 - lane));
+  t = wave_clean_desc(t, lane);  // top-64 of all maxima, identical in every wave
+  const float tau = __shfl(t, k_out - 1);
+
+  // 3. candidates >= tau
+  CRS_FOR_EACH_ENTRY({
+    if (id >= 0 && s >= tau) {
+      const int p = atomicAdd(&sh_cnt, 1);
+      if (p < kCap) { sh_cs[p] = s; sh_ci[p] = id; }
+    }
+  })
+  __syncthreads();
+  const int cnt = sh_cnt;
+  if (cnt <= kCap) {
+    // 4. rank = output slot
+    for (int c = tid; c < cnt; c += kThreads) {
+      const float s = sh_cs[c];
+      const IdT id = sh_ci[c];
+      int rank = 0;
+      for (int o = 0; o < cnt; ++o) rank += better<IdT>(sh_cs[o], sh_ci[o], s, id) ? 1 : 0;
+      if (rank < k_out) { os[rank] = s; oi[rank] = (int64_t)id + id_base; }
+    }
+    return;
+  }
+
+  // ---- fallback: k_out rounds of "largest key strictly below the previous winner"
   float last_s = __builtin_huge_valf();
   IdT last_i = (IdT)-1;
   for (int r = 0; r < k_out; ++r) {
     float bs = kNegInf;
-    IdT bi = kWorstId;
-    bool have = false;
-    for (int e = tid; e < m; e += kThreads) {
-      const int list = e / k_in, j = e - list * k_in;
-      const size_t at = ((size_t)list * nq + q) * k_in + j;
-      const IdT id = ids[at];
-      const float s = scores[at];
-      if (id < 0) continue;
-      // strictly after the previous winner in the total order
+    IdT bi = (IdT)-1;
+    CRS_FOR_EACH_ENTRY({
       const bool after = (s < last_s) || (s == last_s && id > last_i);
-      if (after && (!have || better<IdT>(s, id, bs, bi))) {
-        bs = s; bi = id; have = true;
-      }
-    }
-    if (!have) { bs = kNegInf; bi = (IdT)-1; }
-    // wave reduction; "absent" candidates carry id -1 and lose to any present one
+      if (id >= 0 && after && (bi < 0 || better<IdT>(s, id, bs, bi))) { bs = s; bi = id; }
+    })
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      const float os = __shfl_xor(bs, off);
-      const IdT oi = __shfl_xor(bi, off);
-      const bool take = (oi >= 0) && (bi < 0 || better<IdT>(os, oi, bs, bi));
-      bs = take ? os : bs;
-      bi = take ? oi : bi;
+      const float os2 = __shfl_xor(bs, off);
+      const IdT oi2 = __shfl_xor(bi, off);
+      const bool take = (oi2 >= 0) && (bi < 0 || better<IdT>(os2, oi2, bs, bi));
+      bs = take ? os2 : bs;
+      bi = take ? oi2 : bi;
     }
     const int pp = r & 1;
-    if (lane == 0) { sh_s[pp][wave] = bs; sh_i[pp][wave] = bi; }
+    if (lane == 0) { sh_rs[pp][wave] = bs; sh_ri[pp][wave] = bi; }
     __syncthreads();
-    bs = sh_s[pp][0]; bi = sh_i[pp][0];
+    bs = sh_rs[pp][0]; bi = sh_ri[pp][0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const float os = sh_s[pp][w];
-      const IdT oi = sh_i[pp][w];
-      const bool take = (oi >= 0) && (bi < 0 || better<IdT>(os, oi, bs, bi));
-      bs = take ? os : bs;
-      bi = take ? oi : bi;
+      const float os2 = sh_rs[pp][w];
+      const IdT oi2 = sh_ri[pp][w];
+      const bool take = (oi2 >= 0) && (bi < 0 || better<IdT>(os2, oi2, bs, bi));
+      bs = take ? os2 : bs;
+      bi = take ? oi2 : bi;
     }
-    if (tid == 0) {
-      out_s[(size_t)q * k_out + r] = (bi >= 0) ? bs : kNegInf;
-      out_i[(size_t)q * k_out + r] = (bi >= 0) ? (int64_t)bi + id_base : (int64_t)-1;
-    }
-    if (bi < 0) {
-      // exhausted: fill the tail and stop (uniform across the workgroup)
-      if (tid == 0)
-        for (int rr = r + 1; rr < k_out; ++rr) {
-          out_s[(size_t)q * k_out + rr] = kNegInf;
-          out_i[(size_t)q * k_out + rr] = -1;
-        }
-      break;
-    }
+    if (bi < 0) break;  // exhausted (uniform); the tail already holds (-inf, -1)
+    if (tid == 0) { os[r] = bs; oi[r] = (int64_t)bi + id_base; }
     last_s = bs; last_i = bi;
   }
+#undef CRS_FOR_EACH_ENTRY
 }
 
 }  // namespace
 
+// stage-2 layout: [nq, nlists, k_in] (a query's candidates are contiguous)
 int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,
                      int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream) {
   hipLaunchKernelGGL((merge_kernel<int>), dim3(nq), dim3(kThreads), 0, stream, scores, rows, nlists,
-                     nq, k_in, k_out, id_base, out_scores, out_ids);
+                     k_in, k_out, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids);
   return (int)hipGetLastError();
 }
 
 int merge_launch_i64(const float* scores, const int64_t* ids, int nlists, int nq, int k_in,
                      int k_out, float* out_scores, int64_t* out_ids, hipStream_t stream) {
+  // all-gather layout: [nlists, nq, k_in]
   hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, scores, ids,
-                     nlists, nq, k_in, k_out, (int64_t)0, out_scores, out_ids);
+                     nlists, k_in, k_out, (size_t)nq * k_in, (size_t)k_in, (int64_t)0, out_scores,
+                     out_ids);
   return (int)hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ struct ScanArgs {
   const _Float16* q;      // [nq, D] fp16, zero padded to D
   const void* slab;       // [n_rows, D] fp16 (or int8)
   const float* scales;    // int8 slabs: one fp32 per row, else nullptr
-  float* part_scores;     // [nwg, nq, k]
+  float* part_scores;     // [nq, nwg, k]
   int* part_rows;         // [nwg, nq, k] local row index, -1 = empty
   int n_rows;
   int n_tiles;
@@ -18,6 +18,7 @@ struct ScanArgs {
 };
 
 int scan_tile_rows(int pdim);
+int scan_wg_per_cu();  // resident workgroups per CU the active scan variant is launched with
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
 int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);

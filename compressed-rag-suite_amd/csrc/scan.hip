@@ -29,8 +29,11 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace crs {
+
+int scan_variant();
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -360,9 +363,155 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
   }
 
   if (wave_active) {
-    const size_t o = ((size_t)blockIdx.x * a.nq + (q_valid ? qi : 0)) * a.k;
+    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + blockIdx.x) * a.k;  // [nq, nwg, k]
     compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
   }
+}
+
+// ---------------------------------------------------------------- ring variant (LDS-DMA, deep prefetch)
+// Same math, different staging: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR
+// staging) into a ring of NS stages, NS-1 tiles ahead of the math, one workgroup per CU.  The DMA
+// writes LDS linearly (wave base + lane*16), so the bank swizzle is applied to the per-lane SOURCE
+// address instead; readers use the same involution.  Ordering uses counted vmcnt + a raw s_barrier:
+//     wait  vmcnt((NS-2)*LOADS)   -> this thread's share of tile i has landed
+//     barrier                     -> everyone's share has, and everyone is done reading stage (i-1)%NS
+//     issue tile i+NS-1 into stage (i-1)%NS, then do tile i's math
+// Past the end the clamped addresses turn the prefetch into harmless re-reads, which keeps the
+// vmcnt arithmetic uniform.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int D, int TR, int L, int NS>
+struct RingCfg : Cfg<D, TR, L> {
+  using B = Cfg<D, TR, L>;
+  static constexpr int kLds = NS * B::kTileBytes + 2 * B::kListBytes;
+  static constexpr int kWaitN = (NS - 2) * B::kLoads;
+  static_assert(kWaitN <= 63, "vmcnt field is 6 bits");
+};
+
+template <int D, int TR, int L, int NS>
+__global__ __launch_bounds__(kThreads, 1) void scan_f16_ring_kernel(const ScanArgs a) {
+  using C = RingCfg<D, TR, L, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile_buf = smem;
+  float* sbuf_all = reinterpret_cast<float*>(smem + NS * C::kTileBytes);
+  int* ibuf_all = reinterpret_cast<int*>(smem + NS * C::kTileBytes + C::kListBytes);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15;
+  const int kq = lane >> 4;
+  float* sbuf = sbuf_all + wave * (L * 64);
+  int* ibuf = ibuf_all + wave * (L * 64);
+
+  const int nwg = gridDim.x;
+  const int qi = blockIdx.y * 64 + wave * 16 + lr;
+  const bool q_valid = qi < a.nq;
+  const bool wave_active = (blockIdx.y * 64 + wave * 16) < a.nq;
+
+  f16x8 qf[C::kKsteps];
+  {
+    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 32) : z;
+    }
+    // retire the ordinary loads before the first DMA so no compiler-placed vmcnt(0) lands in the loop
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // source offset (tile relative) of the 16-byte chunk that lands at LDS position P = j*256 + tid
+  int src_off[C::kLoads];
+#pragma unroll
+  for (int j = 0; j < C::kLoads; ++j) {
+    const int P = j * kThreads + tid;
+    const int r = P / C::kCpr, cp = P % C::kCpr;
+    const int c = (cp & ~15) | ((cp ^ r) & 15);
+    src_off[j] = (r * C::kCpr + c) * 16;
+  }
+  int a_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
+
+  const char* slab = reinterpret_cast<const char*>(a.slab);
+  const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
+
+  auto issue = [&](int tile, int stage) {
+    char* sb = tile_buf + stage * C::kTileBytes + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < C::kLoads; ++j) {
+      size_t off = (size_t)tile * C::kTileBytes + (size_t)src_off[j];
+      off = off > last_chunk ? last_chunk : off;
+      __builtin_amdgcn_global_load_lds((gptr_t)(slab + off), (lptr_t)(sb + j * (kThreads * 16)), 16, 0, 0);
+    }
+  };
+
+  float tau = q_valid ? kNegInf : __builtin_huge_valf();
+  int cnt = 0;
+
+  int t = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(t + s * nwg, s);
+
+  int stage = 0;          // stage holding tile t
+  int free_stage = NS - 1;  // stage (i-1) % NS: the one the next issue may overwrite
+  for (; t < a.n_tiles; t += nwg) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::kWaitN) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(t + (NS - 1) * nwg, free_stage);
+    if (wave_active) {
+      const char* buf = tile_buf + stage * C::kTileBytes;
+#pragma unroll
+      for (int rt = 0; rt < C::kRt; ++rt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::kKsteps; ++ks) {
+          const f16x8 af = *reinterpret_cast<const f16x8*>(
+              buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
+        }
+        const int row0 = t * TR + rt * 16 + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sc = acc[i];
+          const int row = row0 + i;
+          if (sc > tau && row < a.n_rows) {
+            sbuf[cnt * 64 + lane] = sc;
+            ibuf[cnt * 64 + lane] = row;
+            ++cnt;
+          }
+        }
+        if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid);
+      }
+    }
+    free_stage = stage;
+    stage = (stage + 1 == NS) ? 0 : stage + 1;
+  }
+  // drain the tail prefetches before the workgroup's LDS can be handed to another one
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (wave_active) {
+    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + blockIdx.x) * a.k;  // [nq, nwg, k]
+    compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
+  }
+}
+
+template <int D, int TR, int L, int NS>
+int launch_ring(const ScanArgs& a, int nwg, hipStream_t stream) {
+  using C = RingCfg<D, TR, L, NS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_f16_ring_kernel<D, TR, L, NS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid(nwg, (a.nq + 63) / 64);
+  hipLaunchKernelGGL((scan_f16_ring_kernel<D, TR, L, NS>), grid, dim3(kThreads), C::kLds, stream, a);
+  return (int)hipGetLastError();
 }
 
 template <int D, int TR, int L>
@@ -382,11 +531,27 @@ int launch_cfg(const ScanArgs& a, int nwg, hipStream_t stream) {
 
 template <int D, int TR>
 int launch_d(const ScanArgs& a, int nwg, hipStream_t stream) {
-  if (a.k <= 16) return launch_cfg<D, TR, 16>(a, nwg, stream);
-  return launch_cfg<D, TR, 32>(a, nwg, stream);
+  if (scan_variant() == 0) {
+    if (a.k <= 16) return launch_cfg<D, TR, 16>(a, nwg, stream);
+    return launch_cfg<D, TR, 32>(a, nwg, stream);
+  }
+  if (a.k <= 16) return launch_ring<D, TR, 16, 4>(a, nwg, stream);
+  return launch_ring<D, TR, 32, 3>(a, nwg, stream);
 }
 
 }  // namespace
+
+// 0 = register-staged double buffer (2 workgroups / CU), 1 = LDS-DMA ring (1 workgroup / CU).
+// CRS_SCAN_VARIANT overrides the default; read once.
+int scan_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CRS_SCAN_VARIANT");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+int scan_wg_per_cu() { return scan_variant() == 0 ? 2 : 1; }
 
 int scan_tile_rows(int pdim) { return pdim <= 512 ? 32 : 16; }
 

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/* in the BUILD container (never on the GPU box).
+
+What pins what:
+  retrieve_cases.json, distance_table.json
+      outputs of the reference's own ContextRetriever (/root/reference/rag/retrieval.py), loaded
+      standalone with stub sibling modules and driven with a duck-typed fake store / embedder.
+      -> pins oracle/retrieve_ref.py AND the product's rag/retrieval.py.
+  encoder_tiny.npz, encoder_minilm.npz, encoder_bge.npz
+      outputs of the container-local transformers.BertModel (the library the reference's
+      sentence-transformers wraps; random-init, weights from oracle/encoder_ref.make_weights)
+      + the published Pooling / Normalize steps.  -> pins oracle/encoder_ref.py.
+  scan_g2.npz
+      exact top-k from an independent torch fp64 matmul + stable sort (ChromaDB itself is not
+      installable here: the search boundary stays "parity unpinned").
+
+Only data (inputs + expected outputs) is written; no reference source text is stored.
+Run:  python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib.util
+import itertools
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def load_reference_retriever():
+    saved = {k: sys.modules.get(k) for k in ("rag", "rag.indexing", "rag.embedding")}
+    for name, attrs in (("rag", {}), ("rag.indexing", {"VectorStore": object}),
+                        ("rag.embedding", {"EmbeddingModel": object})):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location("_ref_retrieval", os.path.join(REF, "rag", "retrieval.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    return mod.ContextRetriever
+
+
+WORDS = ("retrieval augmented generation improves factual grounding of language models by fetching "
+         "passages from a vector index quantization compresses weights to four bits while keeping "
+         "perplexity close to the full precision baseline attention heads mix token information across "
+         "the sequence dense embeddings are compared with cosine similarity and the nearest chunks are "
+         "returned to the prompt what is how does why the a of in").split()
+
+
+def make_text(rng, n_words):
+    return " ".join(rng.choice(WORDS, size=n_words))
+
+
+class FakeCollection:
+    def __init__(self, space):
+        self.metadata = {"hnsw:space": space} if space else {}
+
+
+class FakeStore:
+    """Canned nearest-neighbour list: returns the first top_k entries, ChromaDB-shaped."""
+    def __init__(self, ids, docs, metas, dists, space="cosine", have_collection=True):
+        self.ids, self.docs, self.metas, self.dists = ids, docs, metas, dists
+        self.collection = FakeCollection(space) if have_collection else None
+        self.calls = []
+
+    def search(self, query_embedding, top_k=5, where=None, where_document=None):
+        self.calls.append({"shape": list(np.asarray(query_embedding).shape), "top_k": top_k, "where": where})
+        n = min(top_k, len(self.ids))
+        return {"ids": [self.ids[:n]], "documents": [self.docs[:n]], "metadatas": [self.metas[:n]],
+                "distances": [self.dists[:n]]}
+
+
+class FakeEmbedder:
+    def __init__(self, table, dim):
+        self.table, self.dim = table, dim
+
+    def embed(self, texts, show_progress=False):
+        if isinstance(texts, str):
+            texts = [texts]
+        return np.stack([self.table[t] for t in texts]).astype(np.float32)
+
+
+def gen_retrieve_cases(ContextRetriever):
+    rng = np.random.default_rng(20240611)
+    cases = []
+    dim = 16
+    grid = itertools.product([False, True], [0.0, 0.1, 0.5], [0.0, 0.3, 0.9], [1, 3, 5, 10, 20])
+    for ci, (rr, div, thr, k) in enumerate(grid):
+        n_avail = int(rng.integers(0, 45))
+        if ci % 11 == 0:
+            n_avail = 0
+        dists = np.sort(rng.uniform(0.0, 1.2, size=n_avail)).tolist()
+        if n_avail > 3 and ci % 5 == 0:
+            dists[2] = dists[1]  # an exact tie
+        if n_avail > 1 and ci % 7 == 0:
+            dists[0] = -0.0001  # negative distance: clamp path
+        ids = [f"chunk_{i}" for i in range(n_avail)]
+        docs = [make_text(rng, int(rng.integers(5, 40))) for _ in range(n_avail)]
+        if n_avail > 4 and ci % 3 == 0:
+            docs[3] = docs[0]  # duplicate text -> identical embeddings -> MMR similarity 1
+        metas = [{"page_number": int(rng.integers(1, 15))} for _ in range(n_avail)]
+        query = make_text(rng, int(rng.integers(1, 9)))
+        if ci % 13 == 0:
+            query = ""
+        table = {}
+        for t in docs + [query]:
+            if t not in table:
+                v = rng.standard_normal(dim).astype(np.float32)
+                if ci % 4 == 0:
+                    v = np.abs(v)  # all-positive -> large positive similarities
+                table[t] = v
+        space = ["cosine", "cosine", "l2", "ip", "weird"][ci % 5] if ci % 9 == 0 else "cosine"
+        store = FakeStore(ids, docs, metas, dists, space=space, have_collection=(ci % 6 != 1))
+        emb = FakeEmbedder(table, dim)
+        cfg = {"top_k": 3, "similarity_threshold": thr, "rerank": rr, "diversity_penalty": div}
+        r = ContextRetriever(vector_store=store, embedding_model=emb, config=cfg)
+        use_override = (ci % 2 == 0)
+        got = r.retrieve(query, top_k=k if use_override else None)
+        cases.append({
+            "config": cfg, "top_k_arg": k if use_override else None, "query": query,
+            "space": space, "have_collection": store.collection is not None,
+            "store": {"ids": ids, "documents": docs, "metadatas": metas, "distances": dists},
+            "embeddings": {t: table[t].tolist() for t in table},
+            "search_calls": store.calls,
+            "metric_used": r.distance_metric,
+            "expected": [{"chunk_id": c["chunk_id"], "score": c["score"], "distance": c["distance"],
+                          "rerank_score": c.get("rerank_score"), "text": c["text"], "metadata": c["metadata"]}
+                         for c in got],
+            "expected_context_string": r.get_context_string(query, top_k=k if use_override else None),
+        })
+    return cases
+
+
+def gen_distance_table(ContextRetriever):
+    rows = []
+    for space in ("cosine", "l2", "ip", "other"):
+        store = FakeStore([], [], [], [], space=space)
+        r = ContextRetriever(vector_store=store, embedding_model=None, config={})
+        for d in (-0.1, 0.0, 1e-7, 0.1, 0.12, 0.3, 0.5, 1.0, 1.4142135623730951, 1.9999, 2.0, 2.5, 10.0):
+            rows.append({"metric": space, "distance": d, "similarity": r._distance_to_similarity(d)})
+    return rows
+
+
+def gen_encoder(cfg_name, cfg, batch, seq, seed):
+    import torch
+    from transformers import BertConfig, BertModel
+    from oracle import encoder_ref as er
+    w = er.make_weights(cfg, seed=seed)
+    hf = BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+                    num_attention_heads=cfg.heads, intermediate_size=cfg.ffn,
+                    max_position_embeddings=cfg.max_pos, type_vocab_size=cfg.type_vocab,
+                    layer_norm_eps=cfg.ln_eps, hidden_act="gelu", hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0)
+    model = BertModel(hf, add_pooling_layer=False)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "position_ids" not in m and "token_type_ids" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+    model.eval()
+    ids, mask = er.synth_tokens(cfg, batch, seq, seed=seed + 1)
+    with torch.no_grad():
+        hidden = model(input_ids=torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long(),
+                       token_type_ids=torch.zeros(ids.shape, dtype=torch.long)).last_hidden_state
+        m = torch.from_numpy(mask).float()
+        mean = (hidden * m[..., None]).sum(1) / m.sum(1, keepdim=True).clamp(min=1e-9)
+        cls = hidden[:, 0]
+        out = {
+            "mean_norm": torch.nn.functional.normalize(mean, p=2, dim=1).numpy(),
+            "cls_norm": torch.nn.functional.normalize(cls, p=2, dim=1).numpy(),
+            "mean_raw": mean.numpy(),
+        }
+    np.savez_compressed(os.path.join(OUT, f"encoder_{cfg_name}.npz"), ids=ids, mask=mask, seed=np.int64(seed),
+                        hidden_first_row=hidden[0].numpy().astype(np.float32), **out)
+
+
+def gen_scan():
+    import torch
+    from oracle import scan_ref
+    c = scan_ref.synth_corpus(4096, 384, seed=1234)
+    q = scan_ref.synth_queries(c, 8, seed=4321)
+    c16 = c.astype(np.float16)
+    q16 = q.astype(np.float16)
+    # planted exact duplicates (ties) of the best match of query 0 and query 3
+    f = q16.astype(np.float64) @ c16.astype(np.float64).T
+    for qi, spots in ((0, (7, 2000, 4095)), (3, (1, 2, 3))):
+        b = int(f[qi].argmax())
+        for s in spots:
+            c16[s] = c16[b]
+    full = torch.from_numpy(q16.astype(np.float64)) @ torch.from_numpy(c16.astype(np.float64)).T
+    k = 10
+    # independent of oracle/scan_ref: stable descending sort => equal scores keep ascending id order
+    order = torch.sort(full, dim=1, descending=True, stable=True).indices[:, :k]
+    np.savez_compressed(os.path.join(OUT, "scan_g2.npz"), q16=q16, c16=c16, k=np.int64(k),
+                        ids=order.numpy().astype(np.int64),
+                        scores=torch.gather(full, 1, order).numpy().astype(np.float32))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    CR = load_reference_retriever()
+    with open(os.path.join(OUT, "retrieve_cases.json"), "w") as fh:
+        json.dump(gen_retrieve_cases(CR), fh)
+    with open(os.path.join(OUT, "distance_table.json"), "w") as fh:
+        json.dump(gen_distance_table(CR), fh, indent=1)
+    from oracle import encoder_ref as er
+    gen_encoder("tiny", er.TINY, batch=4, seq=24, seed=11)
+    gen_encoder("minilm", er.MINILM_L6, batch=3, seq=32, seed=12)
+    gen_encoder("bge", er.BGE_BASE, batch=2, seq=16, seed=13)
+    gen_scan()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
