@@ -105,6 +105,7 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.scales = scales;
   a.part_scores = ps;
   a.part_rows = pr;
+  a.stamps = nullptr;
   a.n_rows = (int)n_rows;
   a.n_tiles = p.n_tiles;
   a.nq = nq;

@@ -11,6 +11,7 @@ struct ScanArgs {
   const float* scales;    // int8 slabs: one fp32 per row, else nullptr
   float* part_scores;     // [nq, nwg, k]
   int* part_rows;         // [nwg, nq, k] local row index, -1 = empty
+  unsigned long long* stamps;  // diagnostics only (tools/scan_probe); nullptr in the product path
   int n_rows;
   int n_tiles;
   int nq;

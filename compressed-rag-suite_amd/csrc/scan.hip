@@ -37,8 +37,28 @@ int scan_variant();
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: usable as an asm operand
 
 namespace {
+
+// In-kernel timeline stamps for tools/scan_probe.hip (a separate diagnostic build); no code in the product build.
+#ifdef CRS_STAMPS
+#define CRS_STAMP(slot)                                                                          \
+  do {                                                                                           \
+    if (a.stamps && (threadIdx.x & 63) == 0) {                                                   \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
+      a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (slot)] = t_;                \
+    }                                                                                            \
+  } while (0)
+#define CRS_STAMP_REAL(slot)                                                                     \
+  do {                                                                                           \
+    if (a.stamps && (threadIdx.x & 63) == 0)                                                     \
+      a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CRS_STAMP(slot) do {} while (0)
+#define CRS_STAMP_REAL(slot) do {} while (0)
+#endif
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
@@ -237,7 +257,7 @@ __device__ __forceinline__ void compact(float* __restrict__ sbuf, int* __restric
   }
 }
 
-// ---------------------------------------------------------------- the scan kernel
+// ---------------------------------------------------------------- the scan kernels
 template <int D, int TR, int L>
 struct Cfg {
   static constexpr int kCpr = D / 8;                       // 16-byte chunks per row
@@ -246,13 +266,104 @@ struct Cfg {
   static constexpr int kKsteps = D / 32;
   static constexpr int kRt = TR / 16;
   static constexpr int kListBytes = kWaves * L * 64 * 4;   // per array (scores / rows)
-  static constexpr int kLds = 2 * kTileBytes + 2 * kListBytes;
   static_assert(D % 128 == 0, "row length must be a multiple of 128 elements");
   static_assert(TR % 16 == 0, "tile rows must be a multiple of 16");
   static_assert(kTileBytes % (kThreads * 16) == 0, "tile must split into whole 16-byte loads");
 };
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// What every variant shares: query fragments in VGPRs, the swizzled A-fragment read offsets, the
+// MFMA sweep of one staged tile and the filter/append/compact epilogue.
 template <int D, int TR, int L>
+struct WaveState {
+  using C = Cfg<D, TR, L>;
+  f16x8 qf[C::kKsteps];
+  int a_off[4];
+  float* sbuf;
+  int* ibuf;
+  float tau;
+  int cnt;
+  int lane, lr, kq;
+  bool q_valid;
+#ifdef CRS_STAMPS
+  unsigned long long n_compact = 0, cyc_compact = 0;
+#endif
+
+  __device__ __forceinline__ void init(const ScanArgs& a, int wave, int lane_, float* sbuf_all, int* ibuf_all) {
+    lane = lane_;
+    lr = lane & 15;   // A: row inside the 16-row sub-tile; B/D: query inside the wave's 16
+    kq = lane >> 4;   // A/B: which 8-element k-quarter; D: which group of 4 rows
+    sbuf = sbuf_all + wave * (L * 64);
+    ibuf = ibuf_all + wave * (L * 64);
+    const int qi = blockIdx.y * 64 + wave * 16 + lr;
+    q_valid = qi < a.nq;
+    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 32) : z;
+    }
+    // retire these ordinary loads here, so no compiler-placed vmcnt(0) for them lands in the loop
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) {
+      f16x8 x = qf[ks];
+      asm volatile("" : "+v"(x));
+      qf[ks] = x;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
+    tau = q_valid ? kNegInf : __builtin_huge_valf();
+    cnt = 0;
+  }
+
+  __device__ __forceinline__ void tile(const char* buf, int t, const ScanArgs& a) {
+#pragma unroll
+    for (int rt = 0; rt < C::kRt; ++rt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::kKsteps; ++ks) {
+        const f16x8 af = *reinterpret_cast<const f16x8*>(
+            buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
+      }
+      const int row0 = t * TR + rt * 16 + kq * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float sc = acc[i];
+        const int row = row0 + i;
+        if (sc > tau && row < a.n_rows) {
+          sbuf[cnt * 64 + lane] = sc;
+          ibuf[cnt * 64 + lane] = row;
+          ++cnt;
+        }
+      }
+      if (__any(cnt > L - 4)) {
+#ifdef CRS_STAMPS
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+        compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid);
+#ifdef CRS_STAMPS
+        cyc_compact += __builtin_amdgcn_s_memtime() - t0_;
+        ++n_compact;
+#endif
+      }
+    }
+  }
+
+  __device__ __forceinline__ void finish(const ScanArgs& a, int wave) {
+    const int qi = blockIdx.y * 64 + wave * 16 + lr;
+    const size_t o = ((size_t)(q_valid ? qi : 0) * gridDim.x + blockIdx.x) * a.k;  // [nq, nwg, k]
+    compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
+  }
+};
+
+// ---- variant A: register-staged double buffer, 2 workgroups per CU.
+// ASM_LOADS: issue the next tile's global loads through inline asm right at the top of the
+// iteration (hipcc otherwise sinks plain loads down to the ds_write that consumes them, which
+// serialises HBM latency with the math), and retire them with one hand-placed vmcnt(0).
+template <int D, int TR, int L, bool ASM_LOADS>
 __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a) {
   using C = Cfg<D, TR, L>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -262,29 +373,14 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int lr = lane & 15;  // A: row inside the 16-row sub-tile; B/D: query inside the wave's 16
-  const int kq = lane >> 4;  // A/B: which 8-element k-quarter; D: which group of 4 rows
-  float* sbuf = sbuf_all + wave * (L * 64);
-  int* ibuf = ibuf_all + wave * (L * 64);
-
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = gridDim.x;
-  const int qi = blockIdx.y * 64 + wave * 16 + lr;
-  const bool q_valid = qi < a.nq;
   const bool wave_active = (blockIdx.y * 64 + wave * 16) < a.nq;  // wave-uniform
 
-  // ---- this wave's query fragments, resident in VGPRs for the whole kernel
-  f16x8 qf[C::kKsteps];
-  {
-    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
-#pragma unroll
-    for (int ks = 0; ks < C::kKsteps; ++ks) {
-      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 32) : z;
-    }
-  }
+  CRS_STAMP_REAL(62);
+  CRS_STAMP(0);
 
-  // ---- staging geometry: load j of this thread covers 16-byte chunk P = j*256 + tid of the tile
+  // staging geometry: load j of this thread covers 16-byte chunk P = j*256 + tid of the tile
   int lds_dst[C::kLoads];
 #pragma unroll
   for (int j = 0; j < C::kLoads; ++j) {
@@ -292,106 +388,104 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
     const int r = P / C::kCpr, c = P % C::kCpr;
     lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
   }
-  // A-fragment read offsets for (ks & 3) = 0..3 (row lr, chunk ks*4 + kq, swizzled by row)
-  int a_off[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
-
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
+  const int n_full = a.n_rows / TR;  // tiles that need no clamping
 
-  float tau = q_valid ? kNegInf : __builtin_huge_valf();
-  int cnt = 0;
-
-  uint4 st[C::kLoads];
-  int t = blockIdx.x;
-  if (t < a.n_tiles) {
+  u32x4 st[C::kLoads];
+  auto load_tile = [&](int tile) {
+    if (tile < n_full) {
+      const char* base = slab + (size_t)tile * C::kTileBytes;  // uniform -> SGPR base + 32-bit lane offset
 #pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      size_t off = (size_t)t * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
-      off = off > last_chunk ? last_chunk : off;
-      st[j] = *reinterpret_cast<const uint4*>(slab + off);
-    }
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<uint4*>(tile_buf + lds_dst[j]) = st[j];
-  }
-  __syncthreads();
-
-  int cur = 0;
-  for (; t < a.n_tiles; t += nwg) {
-    // issue the next tile's loads now, park them in LDS after this tile's math (past the
-    // last tile the clamp turns them into harmless re-reads of the slab's final 16 bytes)
-    const int tn = t + nwg;
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      size_t off = (size_t)tn * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
-      off = off > last_chunk ? last_chunk : off;
-      st[j] = *reinterpret_cast<const uint4*>(slab + off);
-    }
-    if (wave_active) {
-      const char* buf = tile_buf + cur * C::kTileBytes;
-#pragma unroll
-      for (int rt = 0; rt < C::kRt; ++rt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < C::kKsteps; ++ks) {
-          const f16x8 af = *reinterpret_cast<const f16x8*>(
-              buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
+      for (int j = 0; j < C::kLoads; ++j) {
+        const unsigned off = (unsigned)(j * kThreads + tid) * 16u;
+        if (ASM_LOADS) {
+          u32x4 x;
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
+          st[j] = x;
+        } else {
+          st[j] = *reinterpret_cast<const u32x4*>(base + off);
         }
-        const int row0 = t * TR + rt * 16 + kq * 4;
+      }
+    } else {  // ragged last tile, or past the end: clamp every lane to the slab's last 16 bytes
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float sc = acc[i];
-          const int row = row0 + i;
-          if (sc > tau && row < a.n_rows) {
-            sbuf[cnt * 64 + lane] = sc;
-            ibuf[cnt * 64 + lane] = row;
-            ++cnt;
-          }
+      for (int j = 0; j < C::kLoads; ++j) {
+        size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
+        off = off > last_chunk ? last_chunk : off;
+        const char* p = slab + off;
+        if (ASM_LOADS) {
+          u32x4 x;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
+          st[j] = x;
+        } else {
+          st[j] = *reinterpret_cast<const u32x4*>(p);
         }
-        if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid);
       }
     }
-    {
-      char* nb = tile_buf + (cur ^ 1) * C::kTileBytes;
+  };
+  auto park_tile = [&](char* dst) {
+    if (ASM_LOADS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<uint4*>(nb + lds_dst[j]) = st[j];
+      for (int j = 0; j < C::kLoads; ++j) {
+        u32x4 x = st[j];
+        asm volatile("" : "+v"(x));
+        st[j] = x;
+      }
     }
-    __syncthreads();
-    cur ^= 1;
-  }
+#pragma unroll
+    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
+  };
 
-  if (wave_active) {
-    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + blockIdx.x) * a.k;  // [nq, nwg, k]
-    compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
+  // first tile's loads go out before the query fragments are fetched, so the two latencies overlap
+  int t = blockIdx.x;
+  load_tile(t);
+  WaveState<D, TR, L> w;
+  w.init(a, wave, lane, sbuf_all, ibuf_all);
+  CRS_STAMP(1);
+  park_tile(tile_buf);
+  __syncthreads();
+  CRS_STAMP(2);
+
+  int cur = 0;
+  int it = 0;
+  for (; t < a.n_tiles; t += nwg) {
+    load_tile(t + nwg);
+    if (wave_active) w.tile(tile_buf + cur * C::kTileBytes, t, a);
+    if (it < 14) CRS_STAMP(3 + 3 * it);
+    park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
+    if (it < 14) CRS_STAMP(4 + 3 * it);
+    __syncthreads();
+    if (it < 14) CRS_STAMP(5 + 3 * it);
+    cur ^= 1;
+    ++it;
   }
+  CRS_STAMP(58);
+  if (wave_active) w.finish(a, wave);
+  CRS_STAMP(59);
+  CRS_STAMP_REAL(63);
+#ifdef CRS_STAMPS
+  if (a.stamps && (threadIdx.x & 63) == 0) {
+    a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + 60] = w.n_compact;
+    a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + 61] = w.cyc_compact;
+  }
+#endif
 }
 
-// ---------------------------------------------------------------- ring variant (LDS-DMA, deep prefetch)
-// Same math, different staging: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR
-// staging) into a ring of NS stages, NS-1 tiles ahead of the math, one workgroup per CU.  The DMA
-// writes LDS linearly (wave base + lane*16), so the bank swizzle is applied to the per-lane SOURCE
-// address instead; readers use the same involution.  Ordering uses counted vmcnt + a raw s_barrier:
+// ---- variant B: LDS-DMA ring.  Tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR
+// staging) into a ring of NS stages, NS-1 tiles ahead of the math.  The DMA writes LDS linearly
+// (wave base + lane*16), so the bank swizzle is applied to the per-lane SOURCE address instead;
+// readers use the same involution.  Ordering uses counted vmcnt + a raw s_barrier:
 //     wait  vmcnt((NS-2)*LOADS)   -> this thread's share of tile i has landed
 //     barrier                     -> everyone's share has, and everyone is done reading stage (i-1)%NS
 //     issue tile i+NS-1 into stage (i-1)%NS, then do tile i's math
 // Past the end the clamped addresses turn the prefetch into harmless re-reads, which keeps the
 // vmcnt arithmetic uniform.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <int D, int TR, int L, int NS>
-struct RingCfg : Cfg<D, TR, L> {
-  using B = Cfg<D, TR, L>;
-  static constexpr int kLds = NS * B::kTileBytes + 2 * B::kListBytes;
-  static constexpr int kWaitN = (NS - 2) * B::kLoads;
+template <int D, int TR, int L, int NS, int WGPC>
+__global__ __launch_bounds__(kThreads, WGPC) void scan_f16_ring_kernel(const ScanArgs a) {
+  using C = Cfg<D, TR, L>;
+  constexpr int kWaitN = (NS - 2) * C::kLoads;
   static_assert(kWaitN <= 63, "vmcnt field is 6 bits");
-};
-
-template <int D, int TR, int L, int NS>
-__global__ __launch_bounds__(kThreads, 1) void scan_f16_ring_kernel(const ScanArgs a) {
-  using C = RingCfg<D, TR, L, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tile_buf = smem;
   float* sbuf_all = reinterpret_cast<float*>(smem + NS * C::kTileBytes);
@@ -400,158 +494,109 @@ __global__ __launch_bounds__(kThreads, 1) void scan_f16_ring_kernel(const ScanAr
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15;
-  const int kq = lane >> 4;
-  float* sbuf = sbuf_all + wave * (L * 64);
-  int* ibuf = ibuf_all + wave * (L * 64);
-
   const int nwg = gridDim.x;
-  const int qi = blockIdx.y * 64 + wave * 16 + lr;
-  const bool q_valid = qi < a.nq;
   const bool wave_active = (blockIdx.y * 64 + wave * 16) < a.nq;
 
-  f16x8 qf[C::kKsteps];
-  {
-    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
-#pragma unroll
-    for (int ks = 0; ks < C::kKsteps; ++ks) {
-      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 32) : z;
-    }
-    // retire the ordinary loads before the first DMA so no compiler-placed vmcnt(0) lands in the loop
-#pragma unroll
-    for (int ks = 0; ks < C::kKsteps; ++ks) asm volatile("" : "+v"(qf[ks]));
-  }
-
   // source offset (tile relative) of the 16-byte chunk that lands at LDS position P = j*256 + tid
-  int src_off[C::kLoads];
+  unsigned src_off[C::kLoads];
 #pragma unroll
   for (int j = 0; j < C::kLoads; ++j) {
     const int P = j * kThreads + tid;
     const int r = P / C::kCpr, cp = P % C::kCpr;
     const int c = (cp & ~15) | ((cp ^ r) & 15);
-    src_off[j] = (r * C::kCpr + c) * 16;
+    src_off[j] = (unsigned)(r * C::kCpr + c) * 16u;
   }
-  int a_off[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
-
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
+  const int n_full = a.n_rows / TR;
 
   auto issue = [&](int tile, int stage) {
     char* sb = tile_buf + stage * C::kTileBytes + wave * 1024;
+    if (tile < n_full) {
+      const char* base = slab + (size_t)tile * C::kTileBytes;
 #pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      size_t off = (size_t)tile * C::kTileBytes + (size_t)src_off[j];
-      off = off > last_chunk ? last_chunk : off;
-      __builtin_amdgcn_global_load_lds((gptr_t)(slab + off), (lptr_t)(sb + j * (kThreads * 16)), 16, 0, 0);
+      for (int j = 0; j < C::kLoads; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + src_off[j]), (lptr_t)(sb + j * (kThreads * 16)), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < C::kLoads; ++j) {
+        size_t off = (size_t)tile * C::kTileBytes + (size_t)src_off[j];
+        off = off > last_chunk ? last_chunk : off;
+        __builtin_amdgcn_global_load_lds((gptr_t)(slab + off), (lptr_t)(sb + j * (kThreads * 16)), 16, 0, 0);
+      }
     }
   };
-
-  float tau = q_valid ? kNegInf : __builtin_huge_valf();
-  int cnt = 0;
 
   int t = blockIdx.x;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(t + s * nwg, s);
+  WaveState<D, TR, L> w;
+  w.init(a, wave, lane, sbuf_all, ibuf_all);  // its vmcnt(0) also retires the prologue DMAs
 
-  int stage = 0;          // stage holding tile t
+  int stage = 0;            // stage holding tile t
   int free_stage = NS - 1;  // stage (i-1) % NS: the one the next issue may overwrite
   for (; t < a.n_tiles; t += nwg) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::kWaitN) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitN) : "memory");
     __builtin_amdgcn_s_barrier();
     issue(t + (NS - 1) * nwg, free_stage);
-    if (wave_active) {
-      const char* buf = tile_buf + stage * C::kTileBytes;
-#pragma unroll
-      for (int rt = 0; rt < C::kRt; ++rt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < C::kKsteps; ++ks) {
-          const f16x8 af = *reinterpret_cast<const f16x8*>(
-              buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
-        }
-        const int row0 = t * TR + rt * 16 + kq * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float sc = acc[i];
-          const int row = row0 + i;
-          if (sc > tau && row < a.n_rows) {
-            sbuf[cnt * 64 + lane] = sc;
-            ibuf[cnt * 64 + lane] = row;
-            ++cnt;
-          }
-        }
-        if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid);
-      }
-    }
+    if (wave_active) w.tile(tile_buf + stage * C::kTileBytes, t, a);
     free_stage = stage;
     stage = (stage + 1 == NS) ? 0 : stage + 1;
   }
   // drain the tail prefetches before the workgroup's LDS can be handed to another one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  if (wave_active) {
-    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + blockIdx.x) * a.k;  // [nq, nwg, k]
-    compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
-  }
+  if (wave_active) w.finish(a, wave);
 }
 
-template <int D, int TR, int L, int NS>
-int launch_ring(const ScanArgs& a, int nwg, hipStream_t stream) {
-  using C = RingCfg<D, TR, L, NS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_f16_ring_kernel<D, TR, L, NS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
+template <typename K>
+int launch_kernel(K kernel, int lds, const ScanArgs& a, int nwg, hipStream_t stream, bool* attr_done) {
+  if (!*attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    *attr_done = true;
   }
   dim3 grid(nwg, (a.nq + 63) / 64);
-  hipLaunchKernelGGL((scan_f16_ring_kernel<D, TR, L, NS>), grid, dim3(kThreads), C::kLds, stream, a);
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, a);
   return (int)hipGetLastError();
 }
 
 template <int D, int TR, int L>
-int launch_cfg(const ScanArgs& a, int nwg, hipStream_t stream) {
+int launch_l(const ScanArgs& a, int nwg, hipStream_t stream) {
   using C = Cfg<D, TR, L>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_f16_kernel<D, TR, L>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
+  constexpr int lists = 2 * C::kListBytes;
+  static bool done[4] = {false, false, false, false};
+  switch (scan_variant()) {
+    case 0: return launch_kernel(&scan_f16_kernel<D, TR, L, false>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[0]);
+    case 3: return launch_kernel(&scan_f16_kernel<D, TR, L, true>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[3]);
+    case 2: return launch_kernel(&scan_f16_ring_kernel<D, TR, L, 2, 2>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[2]);
+    default: {
+      constexpr int NS = (L == 16) ? 4 : 3;
+      return launch_kernel(&scan_f16_ring_kernel<D, TR, L, NS, 1>, NS * C::kTileBytes + lists, a, nwg, stream, &done[1]);
+    }
   }
-  dim3 grid(nwg, (a.nq + 63) / 64);
-  hipLaunchKernelGGL((scan_f16_kernel<D, TR, L>), grid, dim3(kThreads), C::kLds, stream, a);
-  return (int)hipGetLastError();
 }
 
 template <int D, int TR>
 int launch_d(const ScanArgs& a, int nwg, hipStream_t stream) {
-  if (scan_variant() == 0) {
-    if (a.k <= 16) return launch_cfg<D, TR, 16>(a, nwg, stream);
-    return launch_cfg<D, TR, 32>(a, nwg, stream);
-  }
-  if (a.k <= 16) return launch_ring<D, TR, 16, 4>(a, nwg, stream);
-  return launch_ring<D, TR, 32, 3>(a, nwg, stream);
+  if (a.k <= 16) return launch_l<D, TR, 16>(a, nwg, stream);
+  return launch_l<D, TR, 32>(a, nwg, stream);
 }
 
 }  // namespace
 
-// 0 = register-staged double buffer (2 workgroups / CU), 1 = LDS-DMA ring (1 workgroup / CU).
+// 0 = register-staged double buffer (plain loads), 3 = same with asm early loads (2 workgroups/CU);
+// 1 = LDS-DMA ring, 1 workgroup/CU; 2 = LDS-DMA double buffer, 2 workgroups/CU.
 // CRS_SCAN_VARIANT overrides the default; read once.
 int scan_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CRS_SCAN_VARIANT");
-    v = (e && e[0] == '0') ? 0 : 1;
+    v = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : 3;
   }
   return v;
 }
-int scan_wg_per_cu() { return scan_variant() == 0 ? 2 : 1; }
+int scan_wg_per_cu() { return scan_variant() == 1 ? 1 : 2; }
 
 int scan_tile_rows(int pdim) { return pdim <= 512 ? 32 : 16; }
 

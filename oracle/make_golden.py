@@ -129,12 +129,13 @@ def gen_retrieve_cases(ContextRetriever):
         r = ContextRetriever(vector_store=store, embedding_model=emb, config=cfg)
         use_override = (ci % 2 == 0)
         got = r.retrieve(query, top_k=k if use_override else None)
+        calls = [dict(c) for c in store.calls]   # one search per retrieve()
         cases.append({
             "config": cfg, "top_k_arg": k if use_override else None, "query": query,
             "space": space, "have_collection": store.collection is not None,
             "store": {"ids": ids, "documents": docs, "metadatas": metas, "distances": dists},
             "embeddings": {t: table[t].tolist() for t in table},
-            "search_calls": store.calls,
+            "search_calls": calls,
             "metric_used": r.distance_metric,
             "expected": [{"chunk_id": c["chunk_id"], "score": c["score"], "distance": c["distance"],
                           "rerank_score": c.get("rerank_score"), "text": c["text"], "metadata": c["metadata"]}
