@@ -58,6 +58,13 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+namespace crs {
+int set_error(int code, const char* msg) {  // shared with enc_capi.hip
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+}  // namespace crs
+
 extern "C" {
 
 const char* crs_last_error(void) { return g_err; }

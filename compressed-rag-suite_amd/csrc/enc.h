@@ -1,0 +1,26 @@
+// Internal declarations of the encoder translation units (enc_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crs {
+
+// enc_gemm.hip: C = epilogue(A[M,K] W[N,K]^T + bias); mode 0 fp16, 1 GELU fp16, 2 +residual fp32
+int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual,
+                    void* out, int m, int n, int k, int mode, hipStream_t stream);
+
+// enc_attn.hip: ctx[T, H] = softmax(QK^T / sqrt(hd) + padding mask) V per (batch, head);
+// qkv is [T, 3H] fp16 (Q | K | V column blocks), lens[b] real tokens per row (right padding).
+int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,
+                     int heads, hipStream_t stream);
+
+// enc_misc.hip
+int embed_ln_launch(const int* ids, const float* word, const float* pos, const float* type0, const float* g,
+                    const float* b, float eps, int tokens, int seq, int hidden, int vocab, float* x32,
+                    _Float16* x16, hipStream_t stream);
+int layernorm_launch(const float* y, const float* g, const float* b, float eps, int tokens, int hidden,
+                     float* x32, _Float16* x16, hipStream_t stream);
+int pool_launch(const float* x32, const int* lens, int batch, int seq, int hidden, int pooling, int normalize,
+                float* out, hipStream_t stream);
+
+}  // namespace crs

@@ -1,0 +1,127 @@
+// enc_capi.hip -- extern "C" surface of include/crs_encoder.h: the layer loop of the encoder.
+//
+// Per layer (7 launches on one stream, no host sync):
+//   qkv  = x16 Wqkv^T + b                     gemm mode 0      [T, 3H] fp16
+//   ctx  = attention(qkv, lens)               enc_attn.hip     [T, H]  fp16
+//   y32  = ctx Wo^T + b + x32                 gemm mode 2      fp32
+//   x    = LayerNorm(y32)                     -> x32 (fp32 residual stream), x16 (next GEMM input)
+//   ffn  = gelu(x16 Wup^T + b)                gemm mode 1      [T, F] fp16
+//   y32  = ffn Wdown^T + b + x32              gemm mode 2
+//   x    = LayerNorm(y32)
+// then pooling + L2 normalise.  The launch function allocates nothing and never synchronises, so
+// a caller may capture it into a hipGraph for the launch-bound single-query case.
+#include "../../include/crs_encoder.h"
+#include "../../include/crs_hip.h"
+
+#include <stdio.h>
+
+#include "enc.h"
+
+namespace crs {
+int set_error(int code, const char* msg);  // capi.hip
+}
+
+namespace {
+
+size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct Layout {
+  size_t x32, y32, x16, ctx, qkv, ffn, total;
+};
+
+Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
+  const size_t t = (size_t)batch * seq, h = d->hidden, f = d->ffn;
+  Layout l;
+  size_t off = 0;
+  l.x32 = off; off += up256(t * h * 4);
+  l.y32 = off; off += up256(t * h * 4);
+  l.x16 = off; off += up256(t * h * 2);
+  l.ctx = off; off += up256(t * h * 2);
+  l.qkv = off; off += up256(t * 3 * h * 2);
+  l.ffn = off; off += up256(t * f * 2);
+  l.total = off;
+  return l;
+}
+
+int check_desc(const crs_encoder_desc* d) {
+  if (!d) return crs::set_error(CRS_EINVAL, "null descriptor");
+  if (d->hidden <= 0 || d->hidden > 1024 || d->hidden % 64) return crs::set_error(CRS_EINVAL, "hidden must be a multiple of 64, <= 1024");
+  if (d->heads <= 0 || d->hidden % d->heads) return crs::set_error(CRS_EINVAL, "hidden must divide by heads");
+  const int hd = d->hidden / d->heads;
+  if (hd != 16 && hd != 32 && hd != 64) return crs::set_error(CRS_EINVAL, "head_dim must be 16, 32 or 64");
+  if (d->ffn <= 0 || d->ffn % 64) return crs::set_error(CRS_EINVAL, "ffn must be a multiple of 64");
+  if (d->layers <= 0 || d->vocab_size <= 0 || d->max_pos <= 0) return crs::set_error(CRS_EINVAL, "bad layers/vocab/max_pos");
+  if (d->pooling != CRS_POOL_MEAN && d->pooling != CRS_POOL_CLS) return crs::set_error(CRS_EINVAL, "bad pooling mode");
+  return CRS_OK;
+}
+
+#define CRS_TRY(expr, what)                                                             \
+  do {                                                                                  \
+    const int e_ = (expr);                                                              \
+    if (e_ == -1) return crs::set_error(CRS_EINVAL, what ": unsupported shape");        \
+    if (e_) { char m_[160]; snprintf(m_, sizeof m_, what ": %s", hipGetErrorString((hipError_t)e_)); return crs::set_error(CRS_EHIP, m_); } \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int crs_encoder_workspace_bytes(const crs_encoder_desc* d, int batch, int seq, size_t* bytes) {
+  const int rc = check_desc(d);
+  if (rc) return rc;
+  if (!bytes || batch <= 0 || seq <= 0 || seq > d->max_pos) return crs::set_error(CRS_EINVAL, "bad batch/seq (seq <= max_pos)");
+  *bytes = make_layout(d, batch, seq).total;
+  return CRS_OK;
+}
+
+int crs_gemm_f16(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev,
+                 void* out_dev, int m, int n, int k, int mode, void* stream) {
+  if (!a_dev || !w_dev || !out_dev || m <= 0 || n <= 0 || k <= 0) return crs::set_error(CRS_EINVAL, "bad gemm arguments");
+  if (k % 64) return crs::set_error(CRS_EINVAL, "gemm K must be a multiple of 64");
+  if (mode < 0 || mode > 2 || (mode == 2 && !residual_dev)) return crs::set_error(CRS_EINVAL, "bad gemm mode / missing residual");
+  CRS_TRY(crs::gemm_f16_launch((const _Float16*)a_dev, (const _Float16*)w_dev, bias_dev, residual_dev, out_dev, m, n,
+                               k, mode, (hipStream_t)stream), "gemm");
+  return CRS_OK;
+}
+
+int crs_encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights* w, const int32_t* ids_dev,
+                        const int32_t* lens_dev, int batch, int seq, void* workspace_dev,
+                        size_t workspace_bytes, float* out_dev, int normalize, float* hidden_out_dev,
+                        void* stream) {
+  const int rc = check_desc(d);
+  if (rc) return rc;
+  if (!w || !w->layers || !ids_dev || !lens_dev || !workspace_dev || !out_dev) return crs::set_error(CRS_EINVAL, "null pointer");
+  if (batch <= 0 || seq <= 0 || seq > d->max_pos) return crs::set_error(CRS_EINVAL, "bad batch/seq (seq <= max_pos)");
+  const Layout l = make_layout(d, batch, seq);
+  if (workspace_bytes < l.total) return crs::set_error(CRS_ENOSPC, "encoder workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = reinterpret_cast<char*>(workspace_dev);
+  float* x32 = reinterpret_cast<float*>(ws + l.x32);
+  float* y32 = reinterpret_cast<float*>(ws + l.y32);
+  _Float16* x16 = reinterpret_cast<_Float16*>(ws + l.x16);
+  _Float16* ctx = reinterpret_cast<_Float16*>(ws + l.ctx);
+  _Float16* qkv = reinterpret_cast<_Float16*>(ws + l.qkv);
+  _Float16* ffn = reinterpret_cast<_Float16*>(ws + l.ffn);
+  const int T = batch * seq, H = d->hidden, F = d->ffn;
+
+  CRS_TRY(crs::embed_ln_launch(ids_dev, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, d->ln_eps, T,
+                               seq, H, d->vocab_size, x32, x16, st), "embed_ln");
+  for (int li = 0; li < d->layers; ++li) {
+    const crs_encoder_layer& L = w->layers[li];
+    CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, nullptr, qkv, T, 3 * H, H, 0, st), "qkv gemm");
+    CRS_TRY(crs::attention_launch(qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "attention");
+    CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
+    CRS_TRY(crs::layernorm_launch(y32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
+    CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");
+    CRS_TRY(crs::gemm_f16_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, y32, T, H, F, 2, st), "ffn down gemm");
+    CRS_TRY(crs::layernorm_launch(y32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+  }
+  if (hidden_out_dev) {
+    const hipError_t e = hipMemcpyAsync(hidden_out_dev, x32, (size_t)T * H * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return crs::set_error(CRS_EHIP, hipGetErrorString(e));
+  }
+  CRS_TRY(crs::pool_launch(x32, lens_dev, batch, seq, H, d->pooling, normalize, out_dev, st), "pool");
+  return CRS_OK;
+}
+
+}  // extern "C"
