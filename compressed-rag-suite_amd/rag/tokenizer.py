@@ -1,0 +1,123 @@
+"""Host-side BERT tokeniser (uncased basic tokenisation + greedy WordPiece).
+
+The reference gets this from tokenizers==0.22.1 via sentence-transformers (rag/embedding.py:33,65;
+requirements.txt:148); the algorithm restated here is the published BERT one: clean -> lower-case
++ accent strip -> whitespace / punctuation split -> longest-match-first WordPiece with '##'
+continuations, words longer than 100 chars -> [UNK], then [CLS] ... [SEP] with truncation to the
+model's max_seq_length.  ``HashTokenizer`` stands in when no vocab.txt exists (synthetic weights):
+same splitting, ids from a stable hash, so plumbing and benchmarks run fully offline.
+"""
+from __future__ import annotations
+
+import os
+import unicodedata
+import zlib
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+
+def _is_punct(ch: str) -> bool:
+    cp = ord(ch)
+    if 33 <= cp <= 47 or 58 <= cp <= 64 or 91 <= cp <= 96 or 123 <= cp <= 126:
+        return True
+    return unicodedata.category(ch).startswith("P")
+
+
+def _is_cjk(cp: int) -> bool:
+    return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or
+            0x2A700 <= cp <= 0x2B73F or 0x2B740 <= cp <= 0x2B81F or 0x2B820 <= cp <= 0x2CEAF or
+            0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
+
+def basic_tokenize(text: str, lower: bool = True) -> List[str]:
+    cleaned = []
+    for ch in text:
+        cp = ord(ch)
+        if cp == 0 or cp == 0xFFFD or (unicodedata.category(ch) in ("Cc", "Cf") and ch not in "\t\n\r"):
+            continue
+        if _is_cjk(cp):
+            cleaned.append(f" {ch} ")
+        elif ch in " \t\n\r" or unicodedata.category(ch) == "Zs":
+            cleaned.append(" ")
+        else:
+            cleaned.append(ch)
+    words: List[str] = []
+    for tok in "".join(cleaned).split():
+        if lower:
+            tok = tok.lower()
+            tok = "".join(c for c in unicodedata.normalize("NFD", tok) if unicodedata.category(c) != "Mn")
+        cur = ""
+        for ch in tok:
+            if _is_punct(ch):
+                if cur:
+                    words.append(cur)
+                    cur = ""
+                words.append(ch)
+            else:
+                cur += ch
+        if cur:
+            words.append(cur)
+    return words
+
+
+class WordPieceTokenizer:
+    def __init__(self, vocab: Dict[str, int], lower: bool = True, unk="[UNK]", cls="[CLS]", sep="[SEP]", pad="[PAD]"):
+        self.vocab, self.lower = vocab, lower
+        self.unk_id, self.cls_id, self.sep_id = vocab[unk], vocab[cls], vocab[sep]
+        self.pad_id = vocab.get(pad, 0)
+
+    @classmethod
+    def from_vocab_file(cls, path: str, lower: bool = True) -> "WordPieceTokenizer":
+        with open(path, encoding="utf-8") as fh:
+            vocab = {line.rstrip("\n"): i for i, line in enumerate(fh)}
+        return cls(vocab, lower=lower)
+
+    def _wordpiece(self, word: str) -> List[int]:
+        if len(word) > 100:
+            return [self.unk_id]
+        out, start = [], 0
+        while start < len(word):
+            end, found = len(word), None
+            while start < end:
+                piece = ("##" if start else "") + word[start:end]
+                if piece in self.vocab:
+                    found = self.vocab[piece]
+                    break
+                end -= 1
+            if found is None:
+                return [self.unk_id]
+            out.append(found)
+            start = end
+        return out
+
+    def encode(self, text: str, max_len: int) -> List[int]:
+        ids: List[int] = []
+        for w in basic_tokenize(text, self.lower):
+            ids.extend(self._wordpiece(w))
+            if len(ids) >= max_len - 2:
+                break
+        return [self.cls_id] + ids[: max_len - 2] + [self.sep_id]
+
+
+class HashTokenizer:
+    """vocab-free stand-in: one id per basic token, crc32 into [1000, vocab)."""
+
+    def __init__(self, vocab_size: int):
+        self.vocab_size = vocab_size
+        self.cls_id, self.sep_id, self.pad_id = (101, 102, 0) if vocab_size > 1000 else (1, 2, 0)
+        self.lo = 1000 if vocab_size > 2000 else 3
+
+    def encode(self, text: str, max_len: int) -> List[int]:
+        span = self.vocab_size - self.lo
+        ids = [self.lo + zlib.crc32(w.encode("utf-8")) % span for w in basic_tokenize(text)][: max_len - 2]
+        return [self.cls_id] + ids + [self.sep_id]
+
+
+def pad_batch(seqs: Sequence[Sequence[int]], pad_id: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Right-pad to the longest sequence of the batch -> (ids int32 [B, S], lens int32 [B])."""
+    lens = np.array([len(s) for s in seqs], dtype=np.int32)
+    out = np.full((len(seqs), int(lens.max())), pad_id, dtype=np.int32)
+    for r, s in enumerate(seqs):
+        out[r, : len(s)] = s
+    return out, lens
