@@ -5,9 +5,12 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: laun
 torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
 A "step" is one query batch through the retrieve path with everything resident in HBM:
-  [query encoder forward (token ids -> fp32 embeddings), once the encoder backend is built]
+  query encoder forward (token ids [Qb, 16] -> fp32 sentence embeddings; MFMA GEMMs + attention)
   -> normalise + fp16 cast -> exact cosine scan of this rank's slab shard + in-kernel top-k
   -> per-workgroup list merge -> (N > 1) RCCL all-gather of the per-shard top-k + final merge.
+The encoder has the architecture BASELINE.json names for the workload (all-MiniLM-L6-v2 for the
+384-d configs, bge-base-en-v1.5 for the 768-d ones) with seeded random weights and synthetic token
+ids (no checkpoints offline).
 
 Workloads (BASELINE.json configs; --workload):
   c2  100k x 384 fp16 slab per GPU, 64 queries per rank per step, k=10   (default; configs[1])
@@ -30,12 +33,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "compressed-rag-suite_amd"))
 
 WORKLOADS = {
-    #        rows/GPU   dim  Qb   k  slab
-    "c2": (100_000, 384, 64, 10, "f16"),
-    "c3": (1_000_000, 768, 256, 10, "f16"),
-    "c4": (1_250_000, 384, 64, 10, "f16"),
-    "c5": (1_250_000, 768, 64, 10, "i8"),
+    #        rows/GPU   dim  Qb   k  slab  encoder
+    "c2": (100_000, 384, 64, 10, "f16", "minilm"),
+    "c3": (1_000_000, 768, 256, 10, "f16", "bge"),
+    "c4": (1_250_000, 384, 64, 10, "f16", "minilm"),
+    "c5": (1_250_000, 768, 64, 10, "i8", "bge"),
 }
+QUERY_TOKENS = 16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -57,6 +61,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--scan-only", action="store_true", help="diagnostic: skip the encoder (NOT the metric)")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,7 +83,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    rows, dim, qb, k, slab_kind = WORKLOADS[args.workload]
+    rows, dim, qb, k, slab_kind, enc_name = WORKLOADS[args.workload]
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
     pd = nat.padded_dim(dim)
     id_base = rank * rows
@@ -92,15 +97,28 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
-    # ---- queries for this rank: half planted near shard rows, half random (fp32, resident)
-    g = torch.Generator(device=dev); g.manual_seed(4321 + rank)
-    q32 = torch.randn((qb, dim), generator=g, device=dev, dtype=torch.float32)
-    j = torch.randint(0, rows, (qb,), generator=g, device=dev)
-    planted = (torch.arange(qb, device=dev) % 2 == 0)
-    base = slab[j].float()[:, :dim]
-    if slab_type == nat.SLAB_I8:
-        base = base * scales[j][:, None]
-    q32 = torch.where(planted[:, None], base + 0.1 * q32, q32).contiguous()
+    # ---- query encoder (architecture per BASELINE config, seeded random weights) + synthetic token ids
+    from oracle import encoder_ref as er   # weight/token GENERATORS only; nothing of the oracle is timed here
+    from rag._encoder import HipEncoder, ModelShape
+    cfg = er.MINILM_L6 if enc_name == "minilm" else er.BGE_BASE
+    enc_w = er.make_weights(cfg, seed=7)
+    enc = HipEncoder(ModelShape(cfg.vocab_size, cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, cfg.max_pos,
+                                cfg.ln_eps, cfg.pooling, cfg.max_seq), enc_w, device=dev)
+    ids_h, mask_h = er.synth_tokens(cfg, qb, QUERY_TOKENS, seed=4321 + rank, ragged=False)
+    ids_d = torch.from_numpy(ids_h).to(dev)
+    lens_d = torch.from_numpy(mask_h.sum(1).astype(np.int32)).to(dev)
+    q32 = enc.forward(ids_d, lens_d).clone()
+    # plant a near neighbour of every even query into this rank's shard (50 % planted)
+    g = torch.Generator(device=dev); g.manual_seed(99 + rank)
+    j = torch.randperm(rows, generator=g, device=dev)[: qb // 2]
+    planted = q32[0::2] + 0.1 * torch.randn((qb // 2, dim), generator=g, device=dev)
+    tmp = torch.empty((qb // 2, pd), dtype=slab.dtype, device=dev)
+    tmp_sc = torch.empty(qb // 2, dtype=torch.float32, device=dev) if scales is not None else None
+    nat.slab_append_f32(planted.contiguous(), tmp, 0, slab_type, scales=tmp_sc)
+    slab[j] = tmp
+    if scales is not None:
+        scales[j] = tmp_sc
+    q_out = torch.empty((qb, dim), dtype=torch.float32, device=dev)
 
     nq_all = qb * world
     ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k, rows), dtype=torch.uint8, device=dev)
@@ -112,7 +130,8 @@ def main():
         gi = torch.empty((world, nq_all, k), dtype=torch.int64, device=dev)
 
     def step():
-        q16 = nat.queries_to_f16(q32)
+        q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=q_out)
+        q16 = nat.queries_to_f16(q)
         if world > 1:
             dist.all_gather_into_tensor(q_all, q16)
             q16 = q_all
@@ -173,19 +192,25 @@ def main():
         gi_h = gi_.cpu().numpy()
         recall = float(np.mean([scan_ref.recall_at_k(gi_h[r], ri[r]) for r in range(qb)]))
         max_err = float(np.abs(gs_.cpu().numpy() - rs).max())
-        # time the oracle on the bounded sample
-        n_done, t_cpu = 0, 0.0
+        # time the oracle on the bounded sample: encoder (fp32 torch CPU restatement) + exact scan
+        n_done, t_enc, t_scan = 0, 0.0, 0.0
         t_start = time.perf_counter()
-        while t_cpu < args.cpu_seconds:
+        while (t_enc + t_scan) < args.cpu_seconds:
+            ta = time.perf_counter()
+            er.encode_ref(ids_h, mask_h, enc_w, cfg)
+            tb = time.perf_counter()
             scan_ref.cosine_topk_ref(q_h, slab_h, k, scales=sc_h)
+            tc = time.perf_counter()
+            t_enc += tb - ta; t_scan += tc - tb
             n_done += 1
-            t_cpu = time.perf_counter() - t_start
-        # queries/s over the FULL shard: scale the sample's time by rows/sample_rows
-        cpu_qps = (qb * n_done / t_cpu) * (sample_rows / rows)
+        t_cpu = t_enc + t_scan
+        # queries/s over the FULL shard: the scan part of the sample's time scales by rows/sample_rows
+        cpu_qps = qb * n_done / (t_enc + t_scan * (rows / sample_rows))
         cpu = {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": int(torch.get_num_threads()),
                "kind": "port",
-               "sample": f"oracle/scan_ref.cosine_topk_ref (numpy sgemm + exact top-k), {qb} queries x "
-                         f"{sample_rows} of {rows} rows, {n_done} passes in {t_cpu:.1f}s, scaled by rows",
+               "sample": f"oracle encoder_ref.encode_ref ({qb}x{QUERY_TOKENS} tokens, torch fp32) + scan_ref.cosine_topk_ref "
+                         f"(numpy sgemm + exact top-k) over {sample_rows} of {rows} rows; {n_done} passes in "
+                         f"{t_cpu:.1f}s (encoder {t_enc:.1f}s, scan {t_scan:.1f}s), scan time scaled by rows",
                "recall_at_10_gpu_vs_oracle": recall, "max_abs_score_err": max_err}
 
     if rank == 0:
@@ -198,7 +223,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "rows_per_gpu": rows, "corpus_rows": rows * world, "dim": dim,
                        "queries_per_rank_per_step": qb, "queries_per_step": nq_all, "top_k": k,
-                       "slab": slab_kind, "encoder_in_step": False,
+                       "slab": slab_kind, "encoder_in_step": not args.scan_only,
+                       "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
+                       "query_tokens": QUERY_TOKENS,
                        "index_build_s_per_gpu": round(t_build, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

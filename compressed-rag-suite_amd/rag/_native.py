@@ -61,6 +61,9 @@ def load() -> ctypes.CDLL:
             raise NativeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C {os.path.dirname(LIB_PATH)}` -- this path has no CPU fallback")
+        # torch first: it ships its own HIP runtime and both must resolve to ONE libamdhip64 in the
+        # process (loading ours first leaves the kernels on a runtime that sees no device)
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError = header/library mismatch

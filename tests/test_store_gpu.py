@@ -1,0 +1,161 @@
+"""GPU: the drop-in VectorStore / EmbeddingModel / ContextRetriever / RAGPipeline classes against
+the CPU oracle (oracle/retrieve_ref.StoreRef, encoder_ref, retrieve_ref) on the same inputs."""
+import numpy as np
+import pytest
+
+from oracle import encoder_ref as er, retrieve_ref as rr, scan_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _chunks(n, seed=0):
+    from rag.chunking import Chunk
+    rng = np.random.default_rng(seed)
+    words = "alpha beta gamma delta epsilon zeta eta theta iota kappa lambda mu nu xi omicron pi rho sigma".split()
+    out = []
+    for i in range(n):
+        text = " ".join(rng.choice(words, size=int(rng.integers(4, 12))))
+        out.append(Chunk(text=text, chunk_id=f"chunk_{i}", start_char=0, end_char=len(text),
+                         page_number=int(rng.integers(1, 6)), section=None, tokens=len(text.split())))
+    return out
+
+
+def _pair(n=500, d=384, seed=1, **cfg):
+    from rag.indexing import VectorStore
+    chunks = _chunks(n, seed)
+    emb = scan_ref.synth_corpus(n, d, seed=seed)
+    store = VectorStore({"collection_name": "t", **cfg})
+    ref = rr.StoreRef()
+    store.create_index(chunks, emb)
+    ref.create_index(chunks, emb)
+    return store, ref, chunks, emb
+
+
+def test_search_contract_matches_reference_semantics(cuda):
+    store, ref, chunks, emb = _pair()
+    q = scan_ref.synth_queries(emb, 6, seed=9)
+    for i in range(6):
+        got = store.search(q[i:i + 1], top_k=5)
+        exp = ref.search(q[i:i + 1], top_k=5)
+        assert set(got) == {"ids", "documents", "metadatas", "distances"}
+        assert got["ids"] == exp["ids"] and got["documents"] == exp["documents"] and got["metadatas"] == exp["metadatas"]
+        assert np.abs(np.array(got["distances"][0]) - np.array(exp["distances"][0])).max() < 1e-3   # fp16 slab
+        assert got["distances"][0] == sorted(got["distances"][0])
+        assert all(isinstance(x, float) for x in got["distances"][0])
+    # 1-D query, list query and top_k larger than the collection
+    got = store.search(q[0], top_k=3)
+    assert got["ids"] == ref.search(q[0], top_k=3)["ids"]
+    got = store.search(list(map(float, q[0])), top_k=3)
+    assert got["ids"] == ref.search(q[0], top_k=3)["ids"]
+    small, sref, _, e2 = _pair(n=4, seed=3)
+    assert len(small.search(q[0], top_k=10)["ids"][0]) == 4
+    assert small.get_stats()["count"] == 4 and small.get_stats()["metadata"] == {"hnsw:space": "cosine"}
+
+
+def test_errors_and_empty_cases(cuda):
+    from rag.indexing import VectorStore
+    store = VectorStore({})
+    assert store.get_stats() == {"status": "empty", "count": 0}
+    with pytest.raises(ValueError, match="No collection available"):
+        store.search(np.zeros(384, dtype=np.float32))
+    store.create_index([], np.zeros((0, 384), dtype=np.float32))       # warning + no-op
+    assert store.collection is None
+    with pytest.raises(ValueError, match="doesn't match embedding count"):
+        store.create_index(_chunks(3), np.zeros((2, 384), dtype=np.float32))
+    store.create_index(_chunks(3), scan_ref.synth_corpus(3, 384))
+    with pytest.raises(ValueError):
+        store.search(np.zeros(100, dtype=np.float32))                    # wrong dimension
+    store.delete_collection()
+    assert store.collection is None and store.get_stats()["count"] == 0
+    store.reset_collection()
+
+
+def test_incremental_adds_and_filters(cuda):
+    from rag.indexing import VectorStore
+    chunks = _chunks(300, 5)
+    emb = scan_ref.synth_corpus(300, 384, seed=5)
+    store, ref = VectorStore({}), rr.StoreRef()
+    for lo in range(0, 300, 70):                                         # growth / re-allocation path
+        store.create_index(chunks[lo:lo + 70], emb[lo:lo + 70])
+        ref.create_index(chunks[lo:lo + 70], emb[lo:lo + 70])
+    q = scan_ref.synth_queries(emb, 3, seed=6)
+    assert store.search(q[0], top_k=8)["ids"] == ref.search(q[0], top_k=8)["ids"]
+    got = store.search(q[1], top_k=6, where={"page_number": 2})
+    assert got["ids"] == ref.search(q[1], top_k=6, where={"page_number": 2})["ids"]
+    assert all(m["page_number"] == 2 for m in got["metadatas"][0])
+    assert store.search(q[1], top_k=6, where={"page_number": 99})["ids"] == [[]]
+    batch = store.search_batch(q, top_k=4)
+    assert [batch["ids"][i] for i in range(3)] == [ref.search(q[i], top_k=4)["ids"][0] for i in range(3)]
+
+
+def test_refine_fp32_gives_exact_fp32_ranking(cuda):
+    """fp16 storage can flip near-tied ranks; with refine_fp32 the over-fetched candidates are
+    re-scored against the fp32 shadow and the order equals the exact fp32 order."""
+    store, ref, chunks, emb = _pair(n=3000, seed=11, refine_fp32=True)
+    q = scan_ref.synth_queries(emb, 16, seed=12)
+    for i in range(16):
+        got, exp = store.search(q[i], top_k=10), ref.search(q[i], top_k=10)
+        assert got["ids"] == exp["ids"]
+        assert np.abs(np.array(got["distances"][0]) - np.array(exp["distances"][0])).max() < 2e-6
+
+
+def test_persistence_round_trip(cuda, tmp_path):
+    from rag.indexing import VectorStore
+    cfg = {"collection_name": "persisted", "persist_directory": str(tmp_path)}
+    a = VectorStore(cfg)
+    chunks, emb = _chunks(50, 8), scan_ref.synth_corpus(50, 384, seed=8)
+    a.create_index(chunks, emb)
+    q = scan_ref.synth_queries(emb, 1, seed=1)[0]
+    first = a.search(q, top_k=5)
+    b = VectorStore(cfg)                                                 # re-opens the collection
+    assert b.get_stats()["count"] == 50 and b.search(q, top_k=5) == first
+    b.delete_collection()
+    assert VectorStore(cfg).collection is None
+
+
+def test_pipeline_end_to_end_vs_oracle(cuda):
+    """index_documents -> retrieve through the product classes (synthetic MiniLM weights, hash
+    tokeniser) vs oracle encoder + StoreRef + retrieve_ref fed the same token ids."""
+    from rag import RAGPipeline
+    from rag.embedding import synthetic_weights
+    from rag.tokenizer import pad_batch
+    cfg = {"embedding": {"model_name": "synthetic:minilm", "batch_size": 8, "normalize": True, "synthetic_seed": 5},
+           "chunking": {"strategy": "sentence", "chunk_size": 120, "min_chunk_size": 20},
+           "retrieval": {"top_k": 3, "similarity_threshold": 0.0, "rerank": True, "diversity_penalty": 0.1},
+           "vector_store": {"collection_name": "e2e"}}
+    pipe = RAGPipeline(cfg)
+    pipe.setup(model_interface=None)
+    docs = ["Quantization compresses model weights to four bits. Perplexity stays close to the baseline. "
+            "Dense retrieval compares embeddings with cosine similarity. The nearest chunks go to the prompt.",
+            "Attention heads mix token information across the sequence. Retrieval augmented generation grounds "
+            "answers in fetched passages. A vector index stores one embedding per chunk of the document."]
+    secs = pipe.index_documents(docs, show_progress=False)
+    assert secs > 0 and pipe.get_stats()["vector_store"]["count"] >= 4
+    em = pipe.embedding_model
+    shape = em.shape
+    w = synthetic_weights(shape, 5)
+    ocfg = er.EncoderConfig(shape.vocab_size, shape.hidden, shape.layers, shape.heads, shape.ffn, shape.max_pos, 2,
+                            shape.ln_eps, shape.max_seq, shape.pooling)
+
+    def oracle_embed(texts):
+        if isinstance(texts, str):
+            texts = [texts]
+        ids, lens = pad_batch(em.tokenize(texts))
+        mask = (np.arange(ids.shape[1])[None] < lens[:, None]).astype(np.int32)
+        return er.encode_ref(ids, mask, w, ocfg)
+
+    col = pipe.vector_store.collection
+    from rag.chunking import Chunk
+    ref = rr.StoreRef()
+    chunks = [Chunk(t, i, 0, len(t)) for i, t in zip(col.ids, col.documents)]
+    ref.create_index(chunks, oracle_embed(col.documents))
+    ref.metas = col.metadatas
+    for query in ("how does quantization affect perplexity", "what stores the embeddings", "attention heads"):
+        got = pipe.retrieve(query)
+        exp = rr.retrieve(query, search=ref.search, embed=oracle_embed, top_k=3, similarity_threshold=0.0,
+                          do_rerank=True, diversity_penalty=0.1)
+        assert [c["chunk_id"] for c in got] == [c["chunk_id"] for c in exp]
+        assert np.abs(np.array([c["score"] for c in got]) - np.array([c["score"] for c in exp])).max() < 1e-3
+        assert pipe.retrieve_batch([query])[0] == got
+    stats = pipe.get_stats()
+    assert stats["embedding_dim"] == 384 and stats["retrieval"]["distance_metric"] == "cosine"
