@@ -9,6 +9,12 @@ namespace crs {
 int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual,
                     void* out, int m, int n, int k, int mode, hipStream_t stream);
 
+// Panel variant for small M (one K chunk per workgroup, all loads issued at once; split-K over
+// blockIdx.z with fp32 partials [k/kc][M][N] in mode 3, summed by layernorm_launch).
+int gemm_panel_chunk(int k);
+int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
+                      int mode, hipStream_t stream);
+
 // enc_attn.hip: ctx[T, H] = softmax(QK^T / sqrt(hd) + padding mask) V per (batch, head);
 // qkv is [T, 3H] fp16 (Q | K | V column blocks), lens[b] real tokens per row (right padding).
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,
@@ -18,8 +24,10 @@ int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int ba
 int embed_ln_launch(const int* ids, const float* word, const float* pos, const float* type0, const float* g,
                     const float* b, float eps, int tokens, int seq, int hidden, int vocab, float* x32,
                     _Float16* x16, hipStream_t stream);
-int layernorm_launch(const float* y, const float* g, const float* b, float eps, int tokens, int hidden,
-                     float* x32, _Float16* x16, hipStream_t stream);
+// LayerNorm( sum_{s<nsplit} y[s] + bias + residual ): bias / residual may be null (already folded in)
+int layernorm_launch(const float* y, int nsplit, const float* bias, const float* residual, const float* g,
+                     const float* b, float eps, int tokens, int hidden, float* x32, _Float16* x16,
+                     hipStream_t stream);
 int pool_launch(const float* x32, const int* lens, int batch, int seq, int hidden, int pooling, int normalize,
                 float* out, hipStream_t stream);
 

@@ -27,14 +27,24 @@ size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct Layout {
   size_t x32, y32, x16, ctx, qkv, ffn, total;
+  int max_split;
 };
+
+// Small token counts are latency-bound: use the one-shot panel GEMM (+ split-K partials reduced in
+// the LayerNorm); large ones (index build) use the pipelined 128 x 128 kernel.
+constexpr int kPanelMaxTokens = 4096;
+bool use_panel(int tokens, int k) { return tokens <= kPanelMaxTokens && crs::gemm_panel_chunk(k) != 0; }
 
 Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
   const size_t t = (size_t)batch * seq, h = d->hidden, f = d->ffn;
   Layout l;
   size_t off = 0;
+  int split = 1;
+  if (use_panel((int)t, (int)f)) split = (int)f / crs::gemm_panel_chunk((int)f);
+  if (use_panel((int)t, (int)h) && (int)h / crs::gemm_panel_chunk((int)h) > split) split = (int)h / crs::gemm_panel_chunk((int)h);
+  l.max_split = split;
   l.x32 = off; off += up256(t * h * 4);
-  l.y32 = off; off += up256(t * h * 4);
+  l.y32 = off; off += up256(t * h * 4 * split);
   l.x16 = off; off += up256(t * h * 2);
   l.ctx = off; off += up256(t * h * 2);
   l.qkv = off; off += up256(t * 3 * h * 2);
@@ -106,15 +116,29 @@ int crs_encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights* w,
 
   CRS_TRY(crs::embed_ln_launch(ids_dev, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, d->ln_eps, T,
                                seq, H, d->vocab_size, x32, x16, st), "embed_ln");
+  const bool panel_h = use_panel(T, H), panel_f = use_panel(T, F);
+  const bool single_h = panel_h && crs::gemm_panel_chunk(H) == H;   // K = H fits one chunk: fused fp16 epilogues
   for (int li = 0; li < d->layers; ++li) {
     const crs_encoder_layer& L = w->layers[li];
-    CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, nullptr, qkv, T, 3 * H, H, 0, st), "qkv gemm");
+    if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, qkv, T, 3 * H, H, 0, st), "qkv gemm");
+    else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, nullptr, qkv, T, 3 * H, H, 0, st), "qkv gemm");
     CRS_TRY(crs::attention_launch(qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "attention");
-    CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
-    CRS_TRY(crs::layernorm_launch(y32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
-    CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");
-    CRS_TRY(crs::gemm_f16_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, y32, T, H, F, 2, st), "ffn down gemm");
-    CRS_TRY(crs::layernorm_launch(y32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+    if (panel_h) {
+      CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, st), "out gemm");
+      CRS_TRY(crs::layernorm_launch(y32, H / crs::gemm_panel_chunk(H), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
+    } else {
+      CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
+      CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
+    }
+    if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_up, L.b_up, ffn, T, F, H, 1, st), "ffn up gemm");
+    else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");
+    if (panel_f) {
+      CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, st), "ffn down gemm");
+      CRS_TRY(crs::layernorm_launch(y32, F / crs::gemm_panel_chunk(F), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+    } else {
+      CRS_TRY(crs::gemm_f16_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, y32, T, H, F, 2, st), "ffn down gemm");
+      CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+    }
   }
   if (hidden_out_dev) {
     const hipError_t e = hipMemcpyAsync(hidden_out_dev, x32, (size_t)T * H * 4, hipMemcpyDeviceToDevice, st);

@@ -28,6 +28,18 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kThreads = 256;
 constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
 
+// erf-form GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the fp16 rounding of the stored activation); libm's erff costs
+// ~50 VALU instructions per element, this one ~15 with a single v_exp.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = 1.0f / (1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  const float erf = x < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * x * (1.0f + erf);
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {  // 128-byte rows, 8 x 16-byte chunks
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
         if (row >= M) continue;
         float v = acc[i][j][r] + b;
         const size_t at = (size_t)row * N + col;
-        if (MODE == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (MODE == 1) v = gelu_erf(v);
         if (MODE == 2) {
           v += residual[at];
           reinterpret_cast<float*>(out)[at] = v;
@@ -130,6 +142,107 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Panel variant for the launch/latency-bound regime (query batches: M of a few hundred to a few
+// thousand rows).  There the pipelined loop above pays one HBM/L2 round trip per 64-deep K step
+// on a grid far smaller than the chip.  Here a workgroup owns a 64 x 64 output tile and ONE K
+// chunk of <= 384: it issues every load of both operand panels at once as LDS-DMA
+// (global_load_lds_dwordx4, nothing staged in VGPRs), waits once, and runs all its MFMAs out of
+// LDS.  Long contractions are split over blockIdx.z (split-K); the fp32 partial tiles are summed
+// by the LayerNorm kernel that follows anyway (enc_misc.hip), so no extra pass or atomics exist.
+// LDS image: rows of kc halves, 16-byte chunks XOR-swizzled by row inside each 256-byte group;
+// the DMA writes LDS linearly, so the swizzle is applied to the per-lane SOURCE address.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int PM = 64, PN = 64, PKC = 384;
+
+// MODE 0: +bias -> fp16; 1: +bias, GELU -> fp16; 3: raw fp32 partial tile -> out[z][M][N]
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 1) void gemm_panel_kernel(const _Float16* __restrict__ A,
+                                                                const _Float16* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                void* __restrict__ out, int M, int N, int K,
+                                                                int kc) {
+  extern __shared__ __attribute__((aligned(16))) char psm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * PM, n0 = blockIdx.x * PN;
+  const int k0 = blockIdx.z * kc;
+  const int cpr = kc >> 3;                 // 16-byte chunks per panel row (multiple of 16)
+  const int panel_chunks = PM * cpr;       // per operand
+  char* sa = psm;
+  char* sw = psm + panel_chunks * 16;
+
+  // ---- one shot: every chunk of both panels (rows past M / N are clamped; their results are never
+  // stored).  LDS position P = base + tid walks (row, chunk) incrementally: no divisions in the loop.
+  int row = tid / cpr, cp = tid - row * cpr;
+  const int drow = kThreads / cpr, dcp = kThreads - drow * cpr;
+  for (int base = 0; base < panel_chunks; base += kThreads) {
+    const int c = (cp & ~15) | ((cp ^ row) & 15);
+    const int ar = min(m0 + row, M - 1), wr = min(n0 + row, N - 1);
+    const _Float16* ga = A + (size_t)ar * K + k0 + c * 8;
+    const _Float16* gw = W + (size_t)wr * K + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(sa + (base + wave * 64) * 16), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)gw, (lptr_t)(sw + (base + wave * 64) * 16), 16, 0, 0);
+    row += drow;
+    cp += dcp;
+    if (cp >= cpr) { cp -= cpr; ++row; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int arow = wm * 32 + fr, wrow = wn * 32 + fr;
+  const char* pa = sa + arow * (cpr * 16);
+  const char* pw = sw + wrow * (cpr * 16);
+  const int ksteps = kc >> 4;
+#pragma unroll 4
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int c = ks * 2 + fh;
+    const f16x8 af = *reinterpret_cast<const f16x8*>(pa + (((c & ~15) | ((c ^ arow) & 15)) << 4));
+    const f16x8 bf = *reinterpret_cast<const f16x8*>(pw + (((c & ~15) | ((c ^ wrow) & 15)) << 4));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+  }
+
+  const int col = n0 + wn * 32 + fr;
+  if (col < N) {
+    const float b = (MODE != 3 && bias) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (row >= M) continue;
+      float v = acc[r] + b;
+      if (MODE == 1) v = gelu_erf(v);
+      if (MODE == 3)
+        reinterpret_cast<float*>(out)[((size_t)blockIdx.z * M + row) * N + col] = v;
+      else
+        reinterpret_cast<_Float16*>(out)[(size_t)row * N + col] = (_Float16)v;
+    }
+  }
+}
+
+template <int MODE>
+int launch_panel(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
+                 int splitk, hipStream_t stream) {
+  static bool attr_done = false;
+  const int lds = 2 * PM * kc * 2;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PM * PKC * 2);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid((n + PN - 1) / PN, (m + PM - 1) / PM, splitk);
+  hipLaunchKernelGGL((gemm_panel_kernel<MODE>), grid, dim3(kThreads), lds, stream, a, w, bias, out, m, n, k, kc);
+  return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -144,6 +257,31 @@ int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, con
     default: return -1;
   }
   return (int)hipGetLastError();
+}
+
+}  // namespace crs
+
+namespace crs {
+
+// Chunk length for the panel kernel: the largest multiple of 128 that is <= 384 and divides K (0 = none)
+int gemm_panel_chunk(int k) {
+  for (int kc = 384; kc >= 128; kc -= 128)
+    if (k % kc == 0) return kc;
+  return 0;
+}
+
+// out: mode 0/1 fp16 [M,N] (needs k == kc, i.e. a single chunk); mode 3 fp32 [k/kc][M][N] partials
+int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
+                      int mode, hipStream_t stream) {
+  const int kc = gemm_panel_chunk(k);
+  if (kc == 0) return -1;
+  const int splitk = k / kc;
+  switch (mode) {
+    case 0: return splitk == 1 ? launch_panel<0>(a, w, bias, out, m, n, k, kc, 1, stream) : -1;
+    case 1: return splitk == 1 ? launch_panel<1>(a, w, bias, out, m, n, k, kc, 1, stream) : -1;
+    case 3: return launch_panel<3>(a, w, bias, out, m, n, k, kc, splitk, stream);
+    default: return -1;
+  }
 }
 
 }  // namespace crs

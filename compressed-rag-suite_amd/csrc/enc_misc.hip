@@ -9,7 +9,7 @@
 namespace crs {
 namespace {
 
-constexpr int kMaxPerLane = 16;  // hidden <= 1024
+constexpr int kMaxPerLane = 16;  // hidden <= 1024 (generic instantiation); hot shapes get exact counts
 
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
@@ -18,21 +18,22 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 // v[] holds this lane's strided elements (index c = lane + 64*i); normalise and store
-__device__ __forceinline__ void ln_store(float (&v)[kMaxPerLane], int hidden, int lane, const float* g,
+template <int PL>
+__device__ __forceinline__ void ln_store(float (&v)[PL], int hidden, int lane, const float* g,
                                          const float* b, float eps, float* x32, _Float16* x16) {
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) s += (lane + 64 * i < hidden) ? v[i] : 0.f;
+  for (int i = 0; i < PL; ++i) s += (lane + 64 * i < hidden) ? v[i] : 0.f;
   const float mean = wave_sum(s) / hidden;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) {
+  for (int i = 0; i < PL; ++i) {
     const float d = v[i] - mean;
     q += (lane + 64 * i < hidden) ? d * d : 0.f;
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / hidden + eps);
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) {
+  for (int i = 0; i < PL; ++i) {
     const int c = lane + 64 * i;
     if (c < hidden) {
       const float o = (v[i] - mean) * rstd * g[c] + b[c];
@@ -42,6 +43,7 @@ __device__ __forceinline__ void ln_store(float (&v)[kMaxPerLane], int hidden, in
   }
 }
 
+template <int PL>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const float* __restrict__ word,
                                                       const float* __restrict__ pos, const float* __restrict__ type0,
                                                       const float* __restrict__ g, const float* __restrict__ b,
@@ -54,74 +56,93 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const float* w = word + (size_t)id * hidden;
   const float* p = pos + (size_t)(t % seq) * hidden;
-  float v[kMaxPerLane];
+  float v[PL];
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) {
+  for (int i = 0; i < PL; ++i) {
     const int c = lane + 64 * i;
     v[i] = (c < hidden) ? (w[c] + type0[c]) + p[c] : 0.f;   // (word + token_type) + position, as modeling_bert
   }
-  ln_store(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
+  ln_store<PL>(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
 }
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ y, const float* __restrict__ g,
+// y: [nsplit][tokens][hidden] fp32 split-K partial sums of the preceding GEMM (nsplit = 1: the full
+// product); bias / residual are added here when given, so the GEMM needs no epilogue pass.
+template <int PL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ y, int nsplit,
+                                                       const float* __restrict__ bias,
+                                                       const float* residual,   // may alias x32 (in place)
+                                                       const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps, int tokens,
-                                                       int hidden, float* __restrict__ x32,
-                                                       _Float16* __restrict__ x16) {
+                                                       int hidden, float* x32, _Float16* __restrict__ x16) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= tokens) return;
   const float* src = y + (size_t)t * hidden;
-  float v[kMaxPerLane];
+  const size_t split_stride = (size_t)tokens * hidden;
+  float v[PL];
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) {
+  for (int i = 0; i < PL; ++i) {
     const int c = lane + 64 * i;
-    v[i] = (c < hidden) ? src[c] : 0.f;
+    float a = 0.f;
+    if (c < hidden) {
+      a = src[c];
+      for (int sidx = 1; sidx < nsplit; ++sidx) a += src[sidx * split_stride + c];
+      if (bias) a += bias[c];
+      if (residual) a += residual[(size_t)t * hidden + c];
+    }
+    v[i] = a;
   }
-  ln_store(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
+  ln_store<PL>(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
 }
 
-// one wave per sentence: mean over the real tokens (sum / clamp(count, 1e-9)) or the [CLS] row,
-// then x / max(||x||, 1e-12)
+// one 256-thread block per sentence: mean over the real tokens (sum / clamp(count, 1e-9)) or the
+// [CLS] row, then x / max(||x||, 1e-12).  Thread t owns columns t, t+256, ...; the token loop is
+// unrolled so several rows are in flight per thread.
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x32, const int* __restrict__ lens,
                                                   int batch, int seq, int hidden, int pooling, int normalize,
                                                   float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bi >= batch) return;
+  __shared__ float red[4];
+  const int bi = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = x32 + (size_t)bi * seq * hidden;
   int len = lens[bi];
   len = len < 0 ? 0 : (len > seq ? seq : len);
-  float v[kMaxPerLane];
-#pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) v[i] = 0.f;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};   // hidden <= 1024
   if (pooling == 1) {
 #pragma unroll
-    for (int i = 0; i < kMaxPerLane; ++i) {
-      const int c = lane + 64 * i;
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
       if (c < hidden) v[i] = base[c];
     }
   } else {
-    for (int s = 0; s < len; ++s) {
 #pragma unroll
-      for (int i = 0; i < kMaxPerLane; ++i) {
-        const int c = lane + 64 * i;
-        if (c < hidden) v[i] += base[(size_t)s * hidden + c];
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if (c >= hidden) continue;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int s = 0;
+      for (; s + 3 < len; s += 4) {
+        a0 += base[(size_t)s * hidden + c];
+        a1 += base[(size_t)(s + 1) * hidden + c];
+        a2 += base[(size_t)(s + 2) * hidden + c];
+        a3 += base[(size_t)(s + 3) * hidden + c];
       }
+      for (; s < len; ++s) a0 += base[(size_t)s * hidden + c];
+      v[i] = ((a0 + a1) + (a2 + a3)) / fmaxf((float)len, 1e-9f);
     }
-    const float den = fmaxf((float)len, 1e-9f);
-#pragma unroll
-    for (int i = 0; i < kMaxPerLane; ++i) v[i] /= den;
   }
   float scale = 1.f;
   if (normalize) {
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < kMaxPerLane; ++i) q += v[i] * v[i];
-    scale = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    float q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    q = red[0] + red[1] + red[2] + red[3];
+    scale = 1.0f / fmaxf(sqrtf(q), 1e-12f);
   }
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) {
-    const int c = lane + 64 * i;
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
     if (c < hidden) out[(size_t)bi * hidden + c] = v[i] * scale;
   }
 }
@@ -131,21 +152,26 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x32
 int embed_ln_launch(const int* ids, const float* word, const float* pos, const float* type0, const float* g,
                     const float* b, float eps, int tokens, int seq, int hidden, int vocab, float* x32,
                     _Float16* x16, hipStream_t stream) {
-  hipLaunchKernelGGL(embed_ln_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, ids, word, pos, type0, g, b,
-                     eps, tokens, seq, hidden, vocab, x32, x16);
+#define CRS_EMB(PL) hipLaunchKernelGGL((embed_ln_kernel<PL>), dim3((tokens + 3) / 4), dim3(256), 0, stream, ids, word, \
+                                      pos, type0, g, b, eps, tokens, seq, hidden, vocab, x32, x16)
+  if (hidden == 384) CRS_EMB(6); else if (hidden == 768) CRS_EMB(12); else if (hidden <= 64) CRS_EMB(1); else CRS_EMB(16);
+#undef CRS_EMB
   return (int)hipGetLastError();
 }
 
-int layernorm_launch(const float* y, const float* g, const float* b, float eps, int tokens, int hidden,
-                     float* x32, _Float16* x16, hipStream_t stream) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, y, g, b, eps, tokens, hidden,
-                     x32, x16);
+int layernorm_launch(const float* y, int nsplit, const float* bias, const float* residual, const float* g,
+                     const float* b, float eps, int tokens, int hidden, float* x32, _Float16* x16,
+                     hipStream_t stream) {
+#define CRS_LN(PL) hipLaunchKernelGGL((layernorm_kernel<PL>), dim3((tokens + 3) / 4), dim3(256), 0, stream, y, nsplit, \
+                                     bias, residual, g, b, eps, tokens, hidden, x32, x16)
+  if (hidden == 384) CRS_LN(6); else if (hidden == 768) CRS_LN(12); else if (hidden <= 64) CRS_LN(1); else CRS_LN(16);
+#undef CRS_LN
   return (int)hipGetLastError();
 }
 
 int pool_launch(const float* x32, const int* lens, int batch, int seq, int hidden, int pooling, int normalize,
                 float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(pool_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, x32, lens, batch, seq, hidden,
+  hipLaunchKernelGGL(pool_kernel, dim3(batch), dim3(256), 0, stream, x32, lens, batch, seq, hidden,
                      pooling, normalize, out);
   return (int)hipGetLastError();
 }
