@@ -26,6 +26,7 @@ import numpy as np
 
 from rag.chunking import Chunk
 from rag import _native as nat
+from rag import _shard
 
 logger = logging.getLogger(__name__)
 
@@ -119,7 +120,7 @@ class VectorStore:
         self._device = config.get('device', None)
         self.client = self  # the reference keeps a chromadb client here; nothing else reads it
         self.collection: Optional[SlabCollection] = None
-        self._shard_bounds: list = []   # (sidecar start row, rows per rank, batch rows) per sharded add
+        self._shard_map: Optional[_shard.ShardMap] = None
         self._initialize_collection()
 
     # -- helpers -------------------------------------------------------------------------------
@@ -228,10 +229,10 @@ class VectorStore:
             dist = self._dist()
             if dist is not None:
                 # contiguous row shards: rank r keeps rows [lo, hi) of this batch on its GPU
-                w, r = dist.get_world_size(), dist.get_rank()
-                per = -(-len(chunks) // w)
-                lo, hi = min(r * per, len(chunks)), min((r + 1) * per, len(chunks))
-                self._shard_bounds.append((len(col.ids), per, len(chunks)))
+                if self._shard_map is None:
+                    self._shard_map = _shard.ShardMap(dist.get_world_size())
+                lo, hi = _shard.shard_slice(len(chunks), dist.get_world_size(), dist.get_rank())
+                self._shard_map.add_batch(len(col.ids), len(chunks))
                 if hi > lo:
                     col.append_device(emb[lo:hi].contiguous())
             else:
@@ -249,16 +250,6 @@ class VectorStore:
             raise
 
     # -- search --------------------------------------------------------------------------------
-    def _global_row(self, rank: int, local_row: int) -> int:
-        """Row of the host sidecars for (rank, local slab row) under batch-wise contiguous sharding."""
-        for start, per, total in self._shard_bounds:
-            lo = min(rank * per, total)
-            hi = min((rank + 1) * per, total)
-            if local_row < hi - lo:
-                return start + lo + local_row
-            local_row -= hi - lo
-        raise IndexError(local_row)
-
     def _topk_device(self, q32, top_k: int, allowed_rows=None):
         """q32: cuda fp32 [nq, dim] -> (scores [nq,k] fp32, rows [nq,k] int64 host-sidecar rows), cuda."""
         import torch
@@ -292,21 +283,15 @@ class VectorStore:
         if row_map is not None:
             i = torch.where(i >= 0, row_map[i.clamp(min=0)], i)
         if dist is not None:
-            w, r = dist.get_world_size(), dist.get_rank()
-            # local slab row -> sidecar row happens after the merge; tag ids with the rank so the
-            # merged order is (score desc, rank asc, local row asc) == global row order per batch
-            tagged = torch.where(i >= 0, i + (r << 40), i)
-            gs = torch.empty((w, nq, top_k), dtype=torch.float32, device=col.device)
-            gi = torch.empty((w, nq, top_k), dtype=torch.int64, device=col.device)
-            dist.all_gather_into_tensor(gs, s)
-            dist.all_gather_into_tensor(gi, tagged)
-            s, i = nat.merge_topk(gs, gi, top_k)
+            # one RCCL all-gather of the per-shard lists, then the k-way merge kernel on every rank;
+            # wire ids carry the rank so the merged order is (score desc, rank asc, local row asc)
+            s, i = _shard.allgather_merge(dist, s, _shard.tag(i, dist.get_rank()), top_k, nat.merge_topk)
             ih = i.cpu().numpy()
             rows = np.full(ih.shape, -1, dtype=np.int64)
             for a in range(ih.shape[0]):
                 for b in range(ih.shape[1]):
                     if ih[a, b] >= 0:
-                        rows[a, b] = self._global_row(int(ih[a, b] >> 40), int(ih[a, b] & ((1 << 40) - 1)))
+                        rows[a, b] = self._shard_map.global_row(*_shard.untag(int(ih[a, b])))
             i = torch.from_numpy(rows).to(col.device)
         return s, i
 
@@ -397,7 +382,7 @@ class VectorStore:
         """Delete the collection (frees the slab; removes persisted files)."""
         if self.collection:
             self.collection = None
-            self._shard_bounds = []
+            self._shard_map = None
             if self.persist_directory:
                 for path in self._persist_paths():
                     if os.path.exists(path):

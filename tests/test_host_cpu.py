@@ -1,0 +1,194 @@
+"""CPU: host-side logic of the drop-in package (no GPU, no compute calls into the library)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import _cases, assert_case, replay_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- the product ContextRetriever against the reference's own outputs --------------------------------
+class _Col:
+    def __init__(self, space):
+        self.metadata = {"hnsw:space": space}
+
+
+class _Store:
+    def __init__(self, search, space, have_collection):
+        self.search = search
+        self.collection = _Col(space) if have_collection else None
+
+
+class _Emb:
+    def __init__(self, embed):
+        self.embed = embed
+
+
+@pytest.mark.parametrize("idx", range(90))
+def test_product_retriever_matches_reference_golden(idx):
+    from rag.retrieval import ContextRetriever
+    case = _cases()[idx]
+
+    def fn(query, search, embed, cfg, k_arg, metric):
+        r = ContextRetriever(vector_store=_Store(search, case["space"], case["have_collection"]),
+                             embedding_model=_Emb(embed), config=cfg)
+        assert r.distance_metric == metric
+        return r.retrieve(query, top_k=k_arg)
+    got, calls = replay_case(case, fn)
+    assert_case(case, got, calls)
+
+
+def test_product_context_string_and_distance_table():
+    from rag.retrieval import ContextRetriever
+    with open(os.path.join(ROOT, "tests", "golden", "distance_table.json")) as fh:
+        for row in json.load(fh):
+            r = ContextRetriever(_Store(None, row["metric"], True), None, {})
+            assert r._distance_to_similarity(row["distance"]) == row["similarity"]
+    for case in _cases()[:30]:
+        def fn(query, search, embed, cfg, k_arg, metric):
+            r = ContextRetriever(_Store(search, case["space"], case["have_collection"]), _Emb(embed), cfg)
+            return r.get_context_string(query, top_k=k_arg)
+        got, _ = replay_case(case, fn)
+        assert got == case["expected_context_string"]
+
+
+def test_retrieve_batch_equals_retrieve_per_query():
+    from rag.retrieval import ContextRetriever
+    cases = [c for c in _cases() if c["store"]["ids"] and c["query"]][:6]
+    for case in cases:
+        st = case["store"]
+        table = {t: np.asarray(v, dtype=np.float32) for t, v in case["embeddings"].items()}
+
+        class S:
+            collection = _Col("cosine")
+
+            def search(self, query_embedding, top_k=5, where=None, where_document=None):
+                n = min(top_k, len(st["ids"]))
+                return {"ids": [st["ids"][:n]], "documents": [st["documents"][:n]],
+                        "metadatas": [st["metadatas"][:n]], "distances": [st["distances"][:n]]}
+
+            def search_batch(self, q, top_k=5, where=None, where_document=None):
+                one = self.search(None, top_k)
+                return {k: [v[0] for _ in range(len(q))] for k, v in one.items()}
+
+        def embed(texts, show_progress=False):
+            texts = [texts] if isinstance(texts, str) else texts
+            return np.stack([table[t] for t in texts])
+        r = ContextRetriever(S(), _Emb(embed), case["config"])
+        single = r.retrieve(case["query"])
+        batch = r.retrieve_batch([case["query"], case["query"]])
+        strip = lambda cs: [(c["chunk_id"], c["score"], c.get("rerank_score")) for c in cs]
+        assert strip(batch[0]) == strip(single) and strip(batch[1]) == strip(single)
+
+
+# ---- C ABI: the library loads and exports everything the headers declare ----------------------------
+def _declared_symbols():
+    names = set()
+    for h in ("crs_hip.h", "crs_encoder.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(crs_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from rag import _native as nat
+    import rag._encoder  # noqa: F401  (registers the encoder entry points)
+    lib = nat.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 13
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert declared == set(nat.exported_symbols()), "binding table and headers disagree"
+    assert lib.crs_abi_version() == 1
+    assert [lib.crs_padded_dim(d) for d in (1, 100, 128, 384, 768, 1000)] == [128, 128, 128, 384, 768, 1024]
+
+
+def test_argument_validation_without_gpu():
+    """Pure argument checks return error codes before any HIP call."""
+    from rag import _native as nat
+    lib = nat.load()
+    out = ctypes.c_size_t(0)
+    assert lib.crs_scan_workspace_bytes(0, 384, 10, 1000, ctypes.byref(out)) == -1
+    assert lib.crs_scan_workspace_bytes(4, 384, 65, 1000, ctypes.byref(out)) == -1
+    assert b"k must be" in lib.crs_last_error()
+    assert lib.crs_merge_topk(None, None, 1, 1, 1, 1, None, None, None) == -1
+    assert lib.crs_slab_append_f32(None, 5, 384, 7, None, None, None, 0, None) == -1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rag import _native as nat
+    from rag.indexing import VectorStore
+    from rag.embedding import EmbeddingModel
+    from rag.chunking import Chunk
+    with pytest.raises(nat.NativeError):
+        VectorStore({}).create_index([Chunk("a b", "chunk_0", 0, 3)], np.zeros((1, 384), dtype=np.float32))
+    with pytest.raises(nat.NativeError):
+        EmbeddingModel({"model_name": "synthetic:tiny"})
+
+
+# ---- tokenizer / chunker / document processor -----------------------------------------------------------
+def test_wordpiece_tokenizer():
+    from rag.tokenizer import HashTokenizer, WordPieceTokenizer, basic_tokenize, pad_batch
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "un", "##aff", "##able", "hello", ",", "world", "!", "cafe", "##s", "a"]
+    tok = WordPieceTokenizer({t: i for i, t in enumerate(vocab)})
+    assert basic_tokenize("Hello, WORLD!  Café's") == ["hello", ",", "world", "!", "cafe", "'", "s"]
+    assert tok.encode("unaffable", 16) == [2, 4, 5, 6, 3]
+    assert tok.encode("Hello, world!", 16) == [2, 7, 8, 9, 10, 3]
+    assert tok.encode("cafés xyz", 16) == [2, 11, 12, 1, 3]            # accent stripped; unknown word -> [UNK]
+    assert tok.encode("a " * 50, 8) == [2, 13, 13, 13, 13, 13, 13, 3]   # truncation keeps [CLS] / [SEP]
+    assert tok.encode("x" * 101, 8) == [2, 1, 3]                       # > 100 chars -> [UNK]
+    ids, lens = pad_batch([[2, 7, 3], [2, 3]])
+    assert ids.tolist() == [[2, 7, 3], [2, 3, 0]] and lens.tolist() == [3, 2] and ids.dtype == np.int32
+    h = HashTokenizer(30522)
+    a, b = h.encode("the same words", 32), h.encode("the same words", 32)
+    assert a == b and a[0] == 101 and a[-1] == 102 and all(1000 <= t < 30522 for t in a[1:-1])
+
+
+def test_chunker_and_document_processor():
+    from rag.chunking import Chunk, TextChunker
+    from rag.document_processing import DocumentProcessor
+    c = TextChunker({"strategy": "fixed", "chunk_size": 5, "chunk_overlap": 2})
+    chunks = c.chunk("one two three four five six seven eight", page_num=3)
+    assert [x.text for x in chunks] == ["one two three four five", "four five six seven eight", "seven eight"]
+    assert [x.chunk_id for x in chunks] == ["chunk_0", "chunk_1", "chunk_2"] and chunks[0].page_number == 3
+    assert chunks[0].tokens == 5 and isinstance(chunks[0], Chunk)
+    c.reset_chunk_ids()
+    assert c.chunk("x y", 1)[0].chunk_id == "chunk_0"
+    s = TextChunker({"strategy": "sentence", "chunk_size": 30})
+    out = s.chunk("First sentence here. Second one follows. Third.")
+    assert len(out) >= 2 and all(len(x.text) <= 40 for x in out)
+    sem = TextChunker({"strategy": "semantic", "chunk_size": 80, "min_chunk_size": 10, "chunk_overlap": 2})
+    out = sem.chunk("A first paragraph that is long enough to count.\n\nA second paragraph, also long enough.\n\nshort")
+    assert len(out) == 2 and out[1].text.startswith("to count.")
+    assert TextChunker({}).chunk("   ") == []
+    with pytest.raises(ValueError):
+        TextChunker({"strategy": "nope"}).chunk("text")
+    dp = DocumentProcessor({})
+    assert dp.process_string("See   [12] the\nresult (Smith et al., 2020) at https://x.y/z ok") == "See  the result  at  ok"   # like the reference: collapse first, then strip
+    with pytest.raises(FileNotFoundError):
+        dp.process_file("/nonexistent.txt")
+
+
+def test_store_host_logic_shapes():
+    from rag.indexing import VectorStore
+    from rag.chunking import Chunk
+    st = VectorStore({"collection_name": "x"})
+    assert st.collection is None and st.get_stats() == {"status": "empty", "count": 0}
+    with pytest.raises(ValueError, match="No collection available"):
+        st.search(np.zeros(4, dtype=np.float32))
+    with pytest.raises(ValueError, match="doesn't match embedding count"):
+        st.create_index([Chunk("a", "chunk_0", 0, 1)], np.zeros((2, 4), dtype=np.float32))
+    assert st.create_index([], np.zeros((0, 4))) is None
+    meta = VectorStore._chunk_metadata(Chunk("a", "c", 0, 1, page_number=2, section=None, tokens=1), ["page_number", "section", "tokens"])
+    assert meta == {"page_number": 2, "tokens": 1}
+    with pytest.raises(ValueError):
+        VectorStore({"index_dtype": "fp8"})
