@@ -126,8 +126,8 @@ def main():
     out_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
     if world > 1:
         q_all = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
-        gs = torch.empty((world, nq_all, k), dtype=torch.float32, device=dev)
-        gi = torch.empty((world, nq_all, k), dtype=torch.int64, device=dev)
+        gs = torch.empty((world * nq_all, k), dtype=torch.float32, device=dev)
+        gi = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
 
     def step():
         q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=q_out)
@@ -140,7 +140,7 @@ def main():
         if world > 1:
             dist.all_gather_into_tensor(gs, s)
             dist.all_gather_into_tensor(gi, i)
-            s, i = nat.merge_topk(gs, gi, k)
+            s, i = nat.merge_topk(gs.view(world, nq_all, k), gi.view(world, nq_all, k), k)
         return s, i
 
     def sync():

@@ -58,8 +58,10 @@ def allgather_merge(dist, scores, wire_ids, k: int, merge_fn: Callable):
     merge_fn(gathered_scores [W, nq, k], gathered_ids [W, nq, k], k) -> (scores, ids)."""
     import torch
     w = dist.get_world_size()
-    gs = torch.empty((w,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
-    gi = torch.empty((w,) + tuple(wire_ids.shape), dtype=wire_ids.dtype, device=wire_ids.device)
+    nq, kk = scores.shape
+    # flat [W * nq, k] output (concatenation along dim 0) is the form every backend accepts
+    gs = torch.empty((w * nq, kk), dtype=scores.dtype, device=scores.device)
+    gi = torch.empty((w * nq, kk), dtype=wire_ids.dtype, device=wire_ids.device)
     dist.all_gather_into_tensor(gs, scores.contiguous())
     dist.all_gather_into_tensor(gi, wire_ids.contiguous())
-    return merge_fn(gs, gi, k)
+    return merge_fn(gs.view(w, nq, kk), gi.view(w, nq, kk), k)
