@@ -85,7 +85,7 @@ def main():
 
     rows, dim, qb, k, slab_kind, enc_name = WORKLOADS[args.workload]
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
-    pd = nat.padded_dim(dim)
+    pd = nat.padded_dim(dim, slab_type)
     id_base = rank * rows
 
     # ---- index build (untimed): synthetic embeddings -> slab shard in HBM through the product path
@@ -131,7 +131,7 @@ def main():
 
     def step():
         q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=q_out)
-        q16 = nat.queries_to_f16(q)
+        q16 = nat.queries_to_f16(q, slab_type)
         if world > 1:
             dist.all_gather_into_tensor(q_all, q16)
             q16 = q_all
@@ -164,7 +164,7 @@ def main():
     qps = nq_all * args.steps / dt
 
     # ---- roofline of the dominant kernel (the scan), hipEvent-timed on the launch stream
-    q16_all = nat.queries_to_f16(q32) if world == 1 else q_all
+    q16_all = nat.queries_to_f16(q32, slab_type) if world == 1 else q_all
     ms_total, ms_scan = nat.time_cosine_topk(q16_all, slab, rows, dim, k, max(20, min(args.steps, 200)),
                                              slab_type=slab_type, scales=scales)
     elem = 1 if slab_type == nat.SLAB_I8 else 2
@@ -184,9 +184,9 @@ def main():
         sample_rows = min(rows, 200_000)
         slab_h = slab[:sample_rows, :dim].cpu().numpy()
         sc_h = scales[:sample_rows].cpu().numpy() if scales is not None else None
-        q_h = nat.queries_to_f16(q32)[:, :dim].cpu().numpy()
+        q_h = nat.queries_to_f16(q32, slab_type)[:, :dim].cpu().numpy()
         # check the GPU's answer on the sample prefix against the oracle (exactness of the timed path)
-        gs_, gi_ = nat.cosine_topk(nat.queries_to_f16(q32), slab, sample_rows, dim, k, slab_type=slab_type,
+        gs_, gi_ = nat.cosine_topk(nat.queries_to_f16(q32, slab_type), slab, sample_rows, dim, k, slab_type=slab_type,
                                    scales=scales)
         rs, ri = scan_ref.cosine_topk_ref(q_h, slab_h, k, scales=sc_h)
         gi_h = gi_.cpu().numpy()

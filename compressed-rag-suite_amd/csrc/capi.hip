@@ -39,14 +39,14 @@ struct Plan {
   size_t part_elems;  // nwg * nq * k
 };
 
-int make_plan(int nq, int dim, int k, int64_t n_rows, Plan* p) {
+int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   if (nq <= 0 || dim <= 0 || dim > 1024) return fail(CRS_EINVAL, "nq must be > 0 and 0 < dim <= 1024");
   if (k <= 0 || k > CRS_MAX_K) return fail(CRS_EINVAL, "k must be in 1..CRS_MAX_K");
   if (n_rows <= 0 || n_rows > 0x7fffffffLL - 64) return fail(CRS_EINVAL, "n_rows must be in 1..2^31-65");
   const int cus = device_cus();
   if (cus <= 0) return fail(CRS_EHIP, "no HIP device available%s");
-  p->pdim = crs_padded_dim(dim);
-  p->tile_rows = crs::scan_tile_rows(p->pdim);
+  p->pdim = crs_row_elems(dim, slab_type);
+  p->tile_rows = slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
   const int cap = cus * crs::scan_wg_per_cu();
   p->nwg = p->n_tiles < cap ? p->n_tiles : cap;
@@ -69,7 +69,12 @@ extern "C" {
 
 const char* crs_last_error(void) { return g_err; }
 int crs_abi_version(void) { return 1; }
-int crs_padded_dim(int dim) { return dim <= 0 ? 0 : (dim + 127) / 128 * 128; }
+int crs_row_elems(int dim, int slab_type) {
+  if (dim <= 0) return 0;
+  const int g = slab_type == CRS_SLAB_I8 ? 256 : 128;
+  return (dim + g - 1) / g * g;
+}
+int crs_padded_dim(int dim) { return crs_row_elems(dim, CRS_SLAB_F16); }
 
 int crs_slab_append_f32(const float* emb_dev, int64_t n, int dim, int slab_type, void* slab_dev,
                         float* scales_dev, float* shadow_f32_dev, int64_t row0, void* stream) {
@@ -78,16 +83,17 @@ int crs_slab_append_f32(const float* emb_dev, int64_t n, int dim, int slab_type,
   if (n == 0) return CRS_OK;
   if (!emb_dev || !slab_dev) return fail(CRS_EINVAL, "null pointer");
   if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
-  const int e = crs::slab_append_launch(emb_dev, n, dim, crs_padded_dim(dim), slab_type, slab_dev,
+  const int e = crs::slab_append_launch(emb_dev, n, dim, crs_row_elems(dim, slab_type), slab_type, slab_dev,
                                         scales_dev, shadow_f32_dev, row0, (hipStream_t)stream);
   return e ? hip_fail((hipError_t)e, "slab_append") : CRS_OK;
 }
 
-int crs_queries_to_f16(const float* q_dev, int nq, int dim, void* q16_dev, void* stream) {
+int crs_queries_to_f16(const float* q_dev, int nq, int dim, int slab_type, void* q16_dev, void* stream) {
   if (nq < 0 || dim <= 0 || dim > 1024) return fail(CRS_EINVAL, "bad nq/dim");
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
   if (nq == 0) return CRS_OK;
   if (!q_dev || !q16_dev) return fail(CRS_EINVAL, "null pointer");
-  const int e = crs::queries_to_f16_launch(q_dev, nq, dim, crs_padded_dim(dim),
+  const int e = crs::queries_to_f16_launch(q_dev, nq, dim, crs_row_elems(dim, slab_type),
                                            reinterpret_cast<_Float16*>(q16_dev), (hipStream_t)stream);
   return e ? hip_fail((hipError_t)e, "queries_to_f16") : CRS_OK;
 }
@@ -95,9 +101,11 @@ int crs_queries_to_f16(const float* q_dev, int nq, int dim, void* q16_dev, void*
 int crs_scan_workspace_bytes(int nq, int dim, int k, int64_t n_rows, size_t* bytes) {
   if (!bytes) return fail(CRS_EINVAL, "null pointer");
   Plan p;
-  const int rc = make_plan(nq, dim, k, n_rows, &p);
+  const int rc = make_plan(nq, dim, k, n_rows, CRS_SLAB_F16, &p);
   if (rc) return rc;
-  *bytes = 2 * align_up(p.part_elems * 4, 256);
+  // sized for the largest grid either slab type can use (resident workgroups), not for n_rows
+  const size_t cap = (size_t)device_cus() * crs::scan_wg_per_cu();
+  *bytes = 2 * align_up(cap * nq * k * 4, 256);
   return CRS_OK;
 }
 
@@ -128,12 +136,12 @@ int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const v
                     const float* scales_dev, int64_t n_rows, int k, int64_t id_base,
                     void* workspace_dev, size_t workspace_bytes, float* out_scores_dev,
                     int64_t* out_ids_dev, void* stream) {
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
   Plan p;
-  int rc = make_plan(nq, dim, k, n_rows, &p);
+  int rc = make_plan(nq, dim, k, n_rows, slab_type, &p);
   if (rc) return rc;
   if (!q16_dev || !slab_dev || !workspace_dev || !out_scores_dev || !out_ids_dev)
     return fail(CRS_EINVAL, "null pointer");
-  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
   if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
   if (((uintptr_t)q16_dev | (uintptr_t)slab_dev) & 15) return fail(CRS_EINVAL, "q/slab must be 16-byte aligned");
   if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256)) return fail(CRS_ENOSPC, "workspace too small");
@@ -170,8 +178,9 @@ int crs_time_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, co
                          const float* scales_dev, int64_t n_rows, int k, void* workspace_dev,
                          size_t workspace_bytes, float* out_scores_dev, int64_t* out_ids_dev,
                          void* stream, int iters, float* ms_total, float* ms_scan) {
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
   Plan p;
-  int rc = make_plan(nq, dim, k, n_rows, &p);
+  int rc = make_plan(nq, dim, k, n_rows, slab_type, &p);
   if (rc) return rc;
   if (iters <= 0 || !ms_total || !ms_scan) return fail(CRS_EINVAL, "bad iters / null outputs");
   if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256)) return fail(CRS_ENOSPC, "workspace too small");

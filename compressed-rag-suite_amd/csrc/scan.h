@@ -19,6 +19,7 @@ struct ScanArgs {
 };
 
 int scan_tile_rows(int pdim);
+int scan_i8_tile_rows();
 int scan_wg_per_cu();  // resident workgroups per CU the active scan variant is launched with
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);

@@ -22,9 +22,10 @@ _SIGNATURES = {
     "crs_last_error": (c_char_p, []),
     "crs_abi_version": (c_int, []),
     "crs_padded_dim": (c_int, [c_int]),
+    "crs_row_elems": (c_int, [c_int, c_int]),
     "crs_slab_append_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_int64, c_void_p]),
-    "crs_queries_to_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "crs_queries_to_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "crs_scan_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_size_t)]),
     "crs_cosine_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int,
                                 c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
@@ -82,8 +83,9 @@ def check(rc: int) -> None:
         raise NativeError(f"libcrs_hip error {rc}: {msg.decode() if msg else '?'}")
 
 
-def padded_dim(dim: int) -> int:
-    return int(load().crs_padded_dim(int(dim)))
+def padded_dim(dim: int, slab_type: int = SLAB_F16) -> int:
+    """Padded row length of a slab (and of the queries searched against it)."""
+    return int(load().crs_row_elems(int(dim), int(slab_type)))
 
 
 def _stream_ptr():
@@ -109,11 +111,11 @@ def slab_append_f32(emb, slab, row0: int, slab_type: int, scales=None, shadow=No
                                      _ptr(shadow), row0, _stream_ptr()))
 
 
-def queries_to_f16(q32):
+def queries_to_f16(q32, slab_type: int = SLAB_F16):
     import torch
     nq, dim = q32.shape
-    out = torch.empty((nq, padded_dim(dim)), dtype=torch.float16, device=q32.device)
-    check(load().crs_queries_to_f16(_ptr(q32), nq, dim, _ptr(out), _stream_ptr()))
+    out = torch.empty((nq, padded_dim(dim, slab_type)), dtype=torch.float16, device=q32.device)
+    check(load().crs_queries_to_f16(_ptr(q32), nq, dim, slab_type, _ptr(out), _stream_ptr()))
     return out
 
 

@@ -66,7 +66,7 @@ class SlabCollection:
     def _reserve(self, rows: int, dim: int):
         import torch
         if self.dim is None:
-            self.dim, self.pdim = dim, nat.padded_dim(dim)
+            self.dim, self.pdim = dim, nat.padded_dim(dim, self.slab_type)
         elif dim != self.dim:
             raise ValueError(f"Embedding dimension {dim} doesn't match the index dimension {self.dim}")
         if rows <= self.capacity:
@@ -256,7 +256,7 @@ class VectorStore:
         col = self.collection
         dist = self._dist()
         nq = q32.shape[0]
-        q16 = nat.queries_to_f16(q32)
+        q16 = nat.queries_to_f16(q32, col.slab_type)
         slab, scales, shadow, n = col.slab, col.scales, col.shadow, col.n
         row_map = None
         if allowed_rows is not None:   # metadata filter: scan a gathered sub-slab, map rows back

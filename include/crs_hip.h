@@ -33,8 +33,12 @@ extern "C" {
 const char* crs_last_error(void);
 int crs_abi_version(void);
 
-/* Rows of the slab are padded to a multiple of 128 elements (zeros); this returns that padded
- * dimension for an embedding dimension `dim` (384 -> 384, 768 -> 768, 100 -> 128). */
+/* Slab rows are zero-padded: fp16 rows to a multiple of 128 elements, int8 rows to a multiple of
+ * 256 (both = whole 256-byte groups for the LDS swizzle).  crs_row_elems returns the padded row
+ * length for an embedding dimension (fp16: 384 -> 384, 100 -> 128; int8: 768 -> 768, 384 -> 512);
+ * crs_padded_dim(dim) == crs_row_elems(dim, CRS_SLAB_F16).  Queries searched against a slab use
+ * the slab's row length. */
+int crs_row_elems(int dim, int slab_type);
 int crs_padded_dim(int dim);
 
 /* ---- index build: replaces collection.add(embeddings=...) -- rag/indexing.py:114-119 ------
@@ -48,13 +52,14 @@ int crs_padded_dim(int dim);
 int crs_slab_append_f32(const float* emb_dev, int64_t n, int dim, int slab_type, void* slab_dev,
                         float* scales_dev, float* shadow_f32_dev, int64_t row0, void* stream);
 
-/* Query side of the same conversion: fp32 [nq, dim] -> normalised fp16 [nq, crs_padded_dim(dim)]. */
-int crs_queries_to_f16(const float* q_dev, int nq, int dim, void* q16_dev, void* stream);
+/* Query side of the same conversion: fp32 [nq, dim] -> normalised fp16 [nq, crs_row_elems(dim, slab_type)]. */
+int crs_queries_to_f16(const float* q_dev, int nq, int dim, int slab_type, void* q16_dev, void* stream);
 
 /* ---- search: replaces collection.query(query_embeddings, n_results) -- rag/indexing.py:171-176
  * Exact cosine top-k of `nq` fp16 queries against `n_rows` slab rows on the current device.
- *   q16_dev   fp16 [nq, pdim]  (pdim = crs_padded_dim(dim)), unit rows, zero padded
+ *   q16_dev   fp16 [nq, pdim]  (pdim = crs_row_elems(dim, slab_type)), unit rows, zero padded
  *   slab_dev  fp16 or int8 [n_rows, pdim]; scales_dev fp32 [n_rows] for CRS_SLAB_I8 else NULL
+ *             (int8: the kernel moves each query to 16-bit fixed point, see csrc/scan_i8.hip)
  *   k         1..CRS_MAX_K; if k > n_rows the tail slots are (-inf, -1)
  *   id_base   added to row indices (the shard's first global row)
  *   out_scores fp32 [nq, k] cosine, descending; out_ids int64 [nq, k]; ties -> lower id first

@@ -48,6 +48,22 @@ def quantize_rows_i8(x: np.ndarray):
     return q, scale
 
 
+def quantize_query_fx16(q16: np.ndarray):
+    """What the int8 scan kernel does to each fp16 query before the integer MFMA (csrc/scan_i8.hip):
+    sq = max|q| / 32512 (fp32), qi = rint(q / sq) in fp32 -> 16-bit fixed point.  Returns
+    (qi int32 [nq, d], sq fp32 [nq]); the query the kernel effectively searches with is qi * sq."""
+    q = np.asarray(q16, dtype=np.float16).astype(np.float32)
+    amax = np.abs(q).max(axis=1)
+    sq = np.where(amax > 0, amax / np.float32(32512.0), np.float32(1.0)).astype(np.float32)
+    qi = np.rint(q / sq[:, None]).astype(np.int32)
+    return qi, sq
+
+
+def dequantized_queries(q16: np.ndarray) -> np.ndarray:
+    qi, sq = quantize_query_fx16(q16)
+    return qi.astype(np.float64) * sq.astype(np.float64)[:, None]
+
+
 def _order(scores: np.ndarray, ids: np.ndarray) -> np.ndarray:
     # score descending, id ascending
     return np.lexsort((ids, -scores.astype(np.float64)))
