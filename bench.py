@@ -170,8 +170,22 @@ def main():
     elem = 1 if slab_type == nat.SLAB_I8 else 2
     alg_bytes = rows * pd * elem + (rows * 4 if slab_type == nat.SLAB_I8 else 0) + nq_all * pd * 2 + nq_all * k * 8
     achieved = alg_bytes / (ms_scan * 1e-3) / 1e9
+    # HBM traffic per launch comes from the committed PMC passes of this same command (bench.py cannot
+    # read hardware counters itself); null when that workload has not been profiled yet
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+            with open(path) as fh:
+                pm = json.load(fh)
+            if args.workload in pm and world == 1:
+                traffic = pm[args.workload]["hbm_read_bytes_per_launch"]
+                traffic_src = os.path.relpath(path, ROOT)
+                break
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "scan_f16_kernel" if slab_type == nat.SLAB_F16 else "scan_i8_kernel",
                 "kernel_ms": round(ms_scan, 5), "scan_plus_merge_ms": round(ms_total, 5),
                 "algorithmic_bytes": int(alg_bytes)}
