@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--scan-only", action="store_true", help="diagnostic: skip the encoder (NOT the metric)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent query batches in flight on separate HIP streams (1 GPU runs only)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,29 +121,33 @@ def main():
     slab[j] = tmp
     if scales is not None:
         scales[j] = tmp_sc
-    q_out = torch.empty((qb, dim), dtype=torch.float32, device=dev)
-
     nq_all = qb * world
-    ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k, rows), dtype=torch.uint8, device=dev)
-    out_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
-    if world > 1:
-        q_all = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
-        gs = torch.empty((world * nq_all, k), dtype=torch.float32, device=dev)
-        gi = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
 
-    def step():
-        q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=q_out)
+    class Ctx:
+        """Buffers of one in-flight query batch (a step touches nothing outside its Ctx + read-only state)."""
+        def __init__(self):
+            self.q_out = torch.empty((qb, dim), dtype=torch.float32, device=dev)
+            self.enc_ws = torch.empty(enc.workspace_bytes(qb, QUERY_TOKENS), dtype=torch.uint8, device=dev)
+            self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k, rows), dtype=torch.uint8, device=dev)
+            self.out_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
+            self.out_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
+            if world > 1:
+                self.q_all = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
+                self.gs = torch.empty((world * nq_all, k), dtype=torch.float32, device=dev)
+                self.gi = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
+
+    def step(c):
+        q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws)
         q16 = nat.queries_to_f16(q, slab_type)
         if world > 1:
-            dist.all_gather_into_tensor(q_all, q16)
-            q16 = q_all
+            dist.all_gather_into_tensor(c.q_all, q16)
+            q16 = c.q_all
         s, i = nat.cosine_topk(q16, slab, rows, dim, k, slab_type=slab_type, scales=scales, id_base=id_base,
-                               workspace=ws, out_scores=out_s, out_ids=out_i)
+                               workspace=c.ws, out_scores=c.out_s, out_ids=c.out_i)
         if world > 1:
-            dist.all_gather_into_tensor(gs, s)
-            dist.all_gather_into_tensor(gi, i)
-            s, i = nat.merge_topk(gs.view(world, nq_all, k), gi.view(world, nq_all, k), k)
+            dist.all_gather_into_tensor(c.gs, s)
+            dist.all_gather_into_tensor(c.gi, i)
+            s, i = nat.merge_topk(c.gs.view(world, nq_all, k), c.gi.view(world, nq_all, k), k)
         return s, i
 
     def sync():
@@ -148,14 +155,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # Throughput mode (1 GPU): S independent batches in flight, each on its own stream with its own buffers,
+    # each step captured once into a hipGraph and replayed (the step is ~45 small launches).  With RCCL
+    # collectives in the step (N > 1) the steps run eagerly on one stream.
+    n_streams = max(1, args.streams) if world == 1 else 1
+    use_graph = (world == 1) and not args.no_graph
+    ctxs = [Ctx() for _ in range(n_streams)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if world == 1 else [torch.cuda.current_stream()]
+    graphs = []
+    torch.cuda.synchronize()
+    for c, st in zip(ctxs, streams):
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                step(c)
+        st.synchronize()
+        if use_graph:
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=st):
+                step(c)
+            graphs.append(g_)
+
+    def run(n):
+        for it in range(n):
+            sidx = it % n_streams
+            if use_graph:
+                with torch.cuda.stream(streams[sidx]):
+                    graphs[sidx].replay()
+            elif world == 1:
+                with torch.cuda.stream(streams[sidx]):
+                    step(ctxs[sidx])
+            else:
+                step(ctxs[0])
+
+    run(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res_s, res_i = step()
+    run(args.steps)
     sync()
     dt = time.perf_counter() - t0
+    res_i = ctxs[0].out_i
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,7 +202,7 @@ def main():
     qps = nq_all * args.steps / dt
 
     # ---- roofline of the dominant kernel (the scan), hipEvent-timed on the launch stream
-    q16_all = nat.queries_to_f16(q32, slab_type) if world == 1 else q_all
+    q16_all = nat.queries_to_f16(q32, slab_type) if world == 1 else ctxs[0].q_all
     ms_total, ms_scan = nat.time_cosine_topk(q16_all, slab, rows, dim, k, max(20, min(args.steps, 200)),
                                              slab_type=slab_type, scales=scales)
     elem = 1 if slab_type == nat.SLAB_I8 else 2
@@ -239,7 +277,7 @@ def main():
                        "queries_per_rank_per_step": qb, "queries_per_step": nq_all, "top_k": k,
                        "slab": slab_kind, "encoder_in_step": not args.scan_only,
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
-                       "query_tokens": QUERY_TOKENS,
+                       "query_tokens": QUERY_TOKENS, "streams_in_flight": n_streams, "hip_graph": use_graph,
                        "index_build_s_per_gpu": round(t_build, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -20,6 +20,9 @@ int hip_fail(hipError_t e, const char* where) {
   return CRS_EHIP;
 }
 
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+size_t align_up16(size_t x) { return (x + 255) / 256 * 256; }
+
 int device_cus() {
   static int cus[64] = {0};
   int dev = 0;
@@ -35,9 +38,14 @@ int device_cus() {
 
 
 struct Plan {
-  int pdim, tile_rows, n_tiles, nwg;
-  size_t part_elems;  // nwg * nq * k
+  int pdim, tile_rows, n_tiles, nwg, kp;
+  size_t part_elems;  // nwg * nq * kp
 };
+
+// slots per (query, workgroup) partial list: k, or 16 when threshold sharing is on (lists may then be
+// dumped unselected)
+int partial_width(int k) { return (crs::scan_share_tau() && k <= 16) ? 16 : k; }
+size_t tau_bytes(int nq) { return align_up16((size_t)nq * 4); }
 
 int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   if (nq <= 0 || dim <= 0 || dim > 1024) return fail(CRS_EINVAL, "nq must be > 0 and 0 < dim <= 1024");
@@ -50,11 +58,12 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
   const int cap = cus * crs::scan_wg_per_cu();
   p->nwg = p->n_tiles < cap ? p->n_tiles : cap;
-  p->part_elems = (size_t)p->nwg * nq * k;
+  p->kp = partial_width(k);
+  p->part_elems = (size_t)p->nwg * nq * p->kp;
   return CRS_OK;
 }
 
-size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 
 }  // namespace
 
@@ -105,15 +114,22 @@ int crs_scan_workspace_bytes(int nq, int dim, int k, int64_t n_rows, size_t* byt
   if (rc) return rc;
   // sized for the largest grid either slab type can use (resident workgroups), not for n_rows
   const size_t cap = (size_t)device_cus() * crs::scan_wg_per_cu();
-  *bytes = 2 * align_up(cap * nq * k * 4, 256);
+  *bytes = 2 * align_up(cap * nq * partial_width(k) * 4, 256) + tau_bytes(nq);
   return CRS_OK;
 }
 
 static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const void* slab,
                     const float* scales, int64_t n_rows, int k, void* ws, hipStream_t st,
                     float** ps_out, int** pr_out) {
-  float* ps = reinterpret_cast<float*>(ws);
-  int* pr = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + align_up(p.part_elems * 4, 256));
+  // workspace: [shared thresholds | partial scores | partial rows]
+  unsigned* tau = reinterpret_cast<unsigned*>(ws);
+  float* ps = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + tau_bytes(nq));
+  int* pr = reinterpret_cast<int*>(reinterpret_cast<char*>(ps) + align_up(p.part_elems * 4, 256));
+  const bool share = crs::scan_share_tau();
+  if (share) {
+    const hipError_t me = hipMemsetAsync(tau, 0, tau_bytes(nq), st);
+    if (me != hipSuccess) return (int)me;
+  }
   crs::ScanArgs a;
   a.q = reinterpret_cast<const _Float16*>(q16);
   a.slab = slab;
@@ -121,6 +137,8 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.part_scores = ps;
   a.part_rows = pr;
   a.stamps = nullptr;
+  a.tau_shared = share ? tau : nullptr;
+  a.kp = p.kp;
   a.n_rows = (int)n_rows;
   a.n_tiles = p.n_tiles;
   a.nq = nq;
@@ -144,14 +162,14 @@ int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const v
     return fail(CRS_EINVAL, "null pointer");
   if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
   if (((uintptr_t)q16_dev | (uintptr_t)slab_dev) & 15) return fail(CRS_EINVAL, "q/slab must be 16-byte aligned");
-  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256)) return fail(CRS_ENOSPC, "workspace too small");
+  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256) + tau_bytes(nq)) return fail(CRS_ENOSPC, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* ps;
   int* pr;
   int e = run_scan(p, q16_dev, nq, slab_type, slab_dev, scales_dev, n_rows, k, workspace_dev, st, &ps, &pr);
   if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
   if (e) return hip_fail((hipError_t)e, "scan launch");
-  e = crs::merge_launch_i32(ps, pr, p.nwg, nq, k, k, id_base, out_scores_dev, out_ids_dev, st);
+  e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, id_base, out_scores_dev, out_ids_dev, st);
   if (e) return hip_fail((hipError_t)e, "merge launch");
   return CRS_OK;
 }
@@ -183,7 +201,7 @@ int crs_time_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, co
   int rc = make_plan(nq, dim, k, n_rows, slab_type, &p);
   if (rc) return rc;
   if (iters <= 0 || !ms_total || !ms_scan) return fail(CRS_EINVAL, "bad iters / null outputs");
-  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256)) return fail(CRS_ENOSPC, "workspace too small");
+  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256) + tau_bytes(nq)) return fail(CRS_ENOSPC, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t e0, e1;
   hipError_t he;

@@ -9,18 +9,21 @@ struct ScanArgs {
   const _Float16* q;      // [nq, D] fp16, zero padded to D
   const void* slab;       // [n_rows, D] fp16 (or int8)
   const float* scales;    // int8 slabs: one fp32 per row, else nullptr
-  float* part_scores;     // [nq, nwg, k]
+  float* part_scores;     // [nq, nwg, kp]
   int* part_rows;         // [nwg, nq, k] local row index, -1 = empty
+  unsigned* tau_shared;   // [nq] order-preserving uint of the best published k-th score (0 = none); may be null
   unsigned long long* stamps;  // diagnostics only (tools/scan_probe); nullptr in the product path
   int n_rows;
   int n_tiles;
   int nq;
   int k;
+  int kp;                 // slots per (query, workgroup) partial list: >= k (16 when k <= 16)
 };
 
 int scan_tile_rows(int pdim);
 int scan_i8_tile_rows();
-int scan_wg_per_cu();  // resident workgroups per CU the active scan variant is launched with
+int scan_wg_per_cu();
+bool scan_share_tau();  // CRS_SCAN_SHARE_TAU=0 disables cross-workgroup threshold sharing  // resident workgroups per CU the active scan variant is launched with
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
 int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);

@@ -65,6 +65,7 @@ struct WaveState {
   int cnt;
   int lane, lr, kq;
   bool q_valid;
+  unsigned* tau_pub;   // this lane's query slot in the shared-threshold array (nullptr: sharing off)
 #ifdef CRS_STAMPS
   unsigned long long n_compact = 0, cyc_compact = 0;
 #endif
@@ -94,6 +95,7 @@ struct WaveState {
     for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
     tau = q_valid ? kNegInf : __builtin_huge_valf();
     cnt = 0;
+    tau_pub = (a.tau_shared && q_valid) ? a.tau_shared + qi : nullptr;
   }
 
   __device__ __forceinline__ void tile(const char* buf, int t, const ScanArgs& a) {
@@ -121,7 +123,7 @@ struct WaveState {
 #ifdef CRS_STAMPS
         const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 #endif
-        compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid);
+        compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0, tau_pub);
 #ifdef CRS_STAMPS
         cyc_compact += __builtin_amdgcn_s_memtime() - t0_;
         ++n_compact;
@@ -132,8 +134,8 @@ struct WaveState {
 
   __device__ __forceinline__ void finish(const ScanArgs& a, int wave) {
     const int qi = blockIdx.y * 64 + wave * 16 + lr;
-    const size_t o = ((size_t)(q_valid ? qi : 0) * gridDim.x + blockIdx.x) * a.k;  // [nq, nwg, k]
-    compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
+    const size_t o = ((size_t)(q_valid ? qi : 0) * gridDim.x + blockIdx.x) * a.kp;  // [nq, nwg, kp]
+    flush_lists<L>(sbuf, ibuf, lane, cnt, tau, a.k, a.kp, a.part_scores + o, a.part_rows + o, q_valid);
   }
 };
 
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
   const int n_full = a.n_rows / TR;  // tiles that need no clamping
 
   u32x4 st[C::kLoads];
+  unsigned tg = 0;   // shared threshold fetched along with the next tile (ASM_LOADS only), applied one tile late
   auto load_tile = [&](int tile) {
     if (tile < n_full) {
       const char* base = slab + (size_t)tile * C::kTileBytes;  // uniform -> SGPR base + 32-bit lane offset
@@ -201,9 +204,17 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
       }
     }
   };
+  auto fetch_tau = [&](const unsigned* p) {
+    if (ASM_LOADS && p) {
+      unsigned x;
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(x) : "v"(p) : "memory");
+      tg = x;
+    }
+  };
   auto park_tile = [&](char* dst) {
     if (ASM_LOADS) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      { unsigned x = tg; asm volatile("" : "+v"(x)); tg = x; }
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
         u32x4 x = st[j];
@@ -229,9 +240,11 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
   int it = 0;
   for (; t < a.n_tiles; t += nwg) {
     load_tile(t + nwg);
+    fetch_tau(w.tau_pub);
     if (wave_active) w.tile(tile_buf + cur * C::kTileBytes, t, a);
     if (it < 14) CRS_STAMP(3 + 3 * it);
     park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
+    if (ASM_LOADS && w.tau_pub) w.tau = fmaxf(w.tau, foreign_tau(tg));
     if (it < 14) CRS_STAMP(4 + 3 * it);
     __syncthreads();
     if (it < 14) CRS_STAMP(5 + 3 * it);
@@ -375,6 +388,18 @@ int scan_variant() {
   return v;
 }
 int scan_wg_per_cu() { return scan_variant() == 1 ? 1 : 2; }
+// Cross-workgroup threshold sharing (scan_common.h) is OFF by default: measured on MI355X it cut the
+// in-loop compactions per wave from 2 to 1 at C2, but the per-tile L1-bypassing poll of the shared
+// word sits in the same in-order vmcnt queue as the tile loads and cost more than it saved
+// (C2 28.8 -> 38.0 us, C4 174 -> 257 us).  CRS_SCAN_SHARE_TAU=1 re-enables it for experiments.
+bool scan_share_tau() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CRS_SCAN_SHARE_TAU");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
 
 int scan_tile_rows(int pdim) { return pdim <= 512 ? 32 : 16; }
 

@@ -143,6 +143,23 @@ __device__ __forceinline__ float kth_of_quad(float (&s)[32], int k) {
   return __shfl(t, src);
 }
 
+// ---------------------------------------------------------------- threshold sharing across workgroups
+// Every wave's tau is the k-th best of a SUBSET of the rows, hence a lower bound on the global k-th
+// best.  Waves publish it with an agent-scope atomic max on an order-preserving integer image of
+// the float; readers (write-through / L1-bypassing loads, one tile late, staleness is harmless) may
+// then drop anything strictly below it.  A foreign tau is applied one ulp lower, so a row that
+// TIES the foreign k-th score still passes (it may precede that entry in row order).
+__device__ __forceinline__ unsigned ord_of(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_of_ord(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ float foreign_tau(unsigned o) {   // strict threshold equivalent to ">= published"
+  return o > 1u ? float_of_ord(o - 1u) : kNegInf;
+}
+
 // ---------------------------------------------------------------- per-wave candidate lists
 // sbuf/ibuf: [L][64] (slot-major, lane-minor => conflict-free 4-byte accesses).
 // On exit (not FINAL) every query keeps exactly min(k, total) candidates, spread round-robin over
@@ -151,7 +168,7 @@ __device__ __forceinline__ float kth_of_quad(float (&s)[32], int k) {
 template <int L, bool FINAL>
 __device__ __forceinline__ void compact(float* __restrict__ sbuf, int* __restrict__ ibuf, int lane,
                                         int& cnt, float& tau, int k, float* out_s, int* out_i,
-                                        bool q_valid) {
+                                        bool q_valid, int kp = 0, unsigned* tau_pub = nullptr) {
   float v[L], s[L];
   int id[L];
 #pragma unroll
@@ -211,7 +228,7 @@ __device__ __forceinline__ void compact(float* __restrict__ sbuf, int* __restric
           out_i[p] = id[j];
         }
       }
-      for (int p = kept + g; p < k; p += 4) {
+      for (int p = kept + g; p < kp; p += 4) {
         out_s[p] = kNegInf;
         out_i[p] = -1;
       }
@@ -227,7 +244,39 @@ __device__ __forceinline__ void compact(float* __restrict__ sbuf, int* __restric
       }
     }
     cnt = (kept - g + 3) >> 2;
-    if (total >= k) tau = tnew;
+    if (total >= k) {
+      tau = fmaxf(tau, tnew);
+      if (tau_pub && g == 0 && q_valid)
+        __hip_atomic_fetch_max(tau_pub, ord_of(tnew), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// End of a wave's stream: hand its candidates to the merge kernel.  When every query of the wave
+// holds <= kp candidates they are dumped as they are (a superset of the wave's top-k: nothing was
+// ever dropped that could rank), skipping the final selection; otherwise one last compaction.
+template <int L>
+__device__ __forceinline__ void flush_lists(float* __restrict__ sbuf, int* __restrict__ ibuf, int lane, int& cnt,
+                                            float& tau, int k, int kp, float* out_s, int* out_i, bool q_valid) {
+  const int total = quad_sum(cnt);
+  if (__any(total > kp)) {
+    compact<L, true>(sbuf, ibuf, lane, cnt, tau, k, out_s, out_i, q_valid, kp);
+    return;
+  }
+  const int qb = lane & 15, g = lane >> 4;
+  const int c0 = __shfl(cnt, qb), c1 = __shfl(cnt, qb + 16), c2 = __shfl(cnt, qb + 32);
+  const int prefix = (g > 0 ? c0 : 0) + (g > 1 ? c1 : 0) + (g > 2 ? c2 : 0);
+  if (!q_valid) return;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    if (j < cnt) {
+      out_s[prefix + j] = sbuf[j * 64 + lane];
+      out_i[prefix + j] = ibuf[j * 64 + lane];
+    }
+  }
+  for (int p = total + g; p < kp; p += 4) {
+    out_s[p] = kNegInf;
+    out_i[p] = -1;
   }
 }
 

@@ -179,6 +179,8 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
 
   float tau = q_valid ? kNegInf : __builtin_huge_valf();
   int cnt = 0;
+  unsigned* tau_pub = (a.tau_shared && q_valid) ? a.tau_shared + qi : nullptr;
+  unsigned tg = 0;
 
   park_tile(0);
   __syncthreads();
@@ -189,6 +191,11 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
 #pragma unroll
     for (int rt = 0; rt < C::kRt; ++rt) sc_use[rt] = sc_cur[rt];
     load_tile(t + nwg);
+    if (tau_pub) {
+      unsigned x;
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(x) : "v"(tau_pub) : "memory");
+      tg = x;
+    }
     if (wave_active) {
       const char* buf = tile_buf + cur * C::kTileBytes;
 #pragma unroll
@@ -212,16 +219,21 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
             ++cnt;
           }
         }
-        if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid);
+        if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0, tau_pub);
       }
     }
     park_tile(cur ^ 1);
+    if (tau_pub) {
+      unsigned x = tg;
+      asm volatile("" : "+v"(x));
+      tau = fmaxf(tau, foreign_tau(x));
+    }
     __syncthreads();
     cur ^= 1;
   }
   if (wave_active) {
-    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + blockIdx.x) * a.k;  // [nq, nwg, k]
-    compact<L, true>(sbuf, ibuf, lane, cnt, tau, a.k, a.part_scores + o, a.part_rows + o, q_valid);
+    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + blockIdx.x) * a.kp;  // [nq, nwg, kp]
+    flush_lists<L>(sbuf, ibuf, lane, cnt, tau, a.k, a.kp, a.part_scores + o, a.part_rows + o, q_valid);
   }
 }
 

@@ -121,7 +121,7 @@ class HipEncoder:
         nat.check(nat.load().crs_encoder_workspace_bytes(byref(self.desc), batch, seq, byref(out)))
         return int(out.value)
 
-    def forward(self, ids, lens, normalize: bool = True, return_hidden: bool = False, out=None):
+    def forward(self, ids, lens, normalize: bool = True, return_hidden: bool = False, out=None, workspace=None):
         """ids: int32 [B, S] (numpy or cuda tensor, right padded), lens: int32 [B].
         Returns cuda fp32 [B, H] (and [B, S, H] hidden states when return_hidden)."""
         import torch
@@ -133,12 +133,17 @@ class HipEncoder:
         lens = lens.to(device=self.device, dtype=torch.int32).contiguous()
         b, s = ids.shape
         need = self.workspace_bytes(b, s)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = workspace
+        if ws is None:   # private scratch; pass `workspace` to run several forwards concurrently on different streams
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws = self._ws
+        elif ws.numel() < need:
+            raise ValueError(f"encoder workspace too small: {ws.numel()} < {need}")
         if out is None:
             out = torch.empty((b, self.shape.hidden), dtype=torch.float32, device=self.device)
         hidden = torch.empty((b, s, self.shape.hidden), dtype=torch.float32, device=self.device) if return_hidden else None
         nat.check(nat.load().crs_encoder_forward(byref(self.desc), byref(self.weights), nat._ptr(ids), nat._ptr(lens),
-                                                 b, s, nat._ptr(self._ws), self._ws.numel(), nat._ptr(out),
+                                                 b, s, nat._ptr(ws), ws.numel(), nat._ptr(out),
                                                  1 if normalize else 0, nat._ptr(hidden), nat._stream_ptr()))
         return (out, hidden) if return_hidden else out

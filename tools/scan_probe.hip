@@ -27,13 +27,17 @@ int main(int argc, char** argv) {
   for (auto& x : hq) x = (_Float16)(rnd() * 0.1f);
   _Float16 *slab, *q; float* ps; int* pr; unsigned long long* st;
   hipMalloc(&slab, h.size() * 2); hipMalloc(&q, hq.size() * 2);
-  hipMalloc(&ps, (size_t)nwg * nq * k * 4); hipMalloc(&pr, (size_t)nwg * nq * k * 4);
+  hipMalloc(&ps, (size_t)nwg * nq * 64 * 4); hipMalloc(&pr, (size_t)nwg * nq * 64 * 4);
   hipMalloc(&st, (size_t)nwg * 4 * 64 * 8);
   hipMemcpy(slab, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(q, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
-  crs::ScanArgs a{q, slab, nullptr, ps, pr, st, rows, n_tiles, nq, k};
+  unsigned* tau; hipMalloc(&tau, nq * 4);
+  crs::ScanArgs a{};
+  a.q = q; a.slab = slab; a.scales = nullptr; a.part_scores = ps; a.part_rows = pr; a.tau_shared = crs::scan_share_tau() ? tau : nullptr;
+  a.stamps = st; a.n_rows = rows; a.n_tiles = n_tiles; a.nq = nq; a.k = k; a.kp = k <= 16 ? 16 : k;
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(st, 0, (size_t)nwg * 4 * 64 * 8);
+    hipMemset(tau, 0, nq * 4);
     int e = crs::scan_launch_f16(a, dim, nwg, 0);
     hipDeviceSynchronize();
     if (e) { printf("launch error %d\n", e); return 1; }
