@@ -33,7 +33,12 @@ struct Layout {
 // Small token counts are latency-bound: use the one-shot panel GEMM (+ split-K partials reduced in
 // the LayerNorm); large ones (index build) use the pipelined 128 x 128 kernel.
 constexpr int kPanelMaxTokens = 4096;
-bool use_panel(int tokens, int k) { return tokens <= kPanelMaxTokens && crs::gemm_panel_chunk(k) != 0; }
+bool use_panel(int tokens, int k) {
+  const int kc = crs::gemm_panel_chunk(k);
+  if (tokens > kPanelMaxTokens || kc == 0) return false;
+  const int ns = k / kc;   // split counts the LayerNorm kernel is instantiated for
+  return ns == 1 || ns == 2 || ns == 3 || ns == 4 || ns == 6 || ns == 8;
+}
 
 Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
   const size_t t = (size_t)batch * seq, h = d->hidden, f = d->ffn;

@@ -33,7 +33,7 @@ constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
 // ~50 VALU instructions per element, this one ~15 with a single v_exp.
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = 1.0f / (1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // 1-ulp reciprocal: one v_rcp_f32
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
   const float erf = x < 0.f ? -erf_abs : erf_abs;
@@ -158,43 +158,52 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int PM = 64, PN = 64, PKC = 384;
+constexpr int PN = 64, PKC = 384;
 
-// MODE 0: +bias -> fp16; 1: +bias, GELU -> fp16; 3: raw fp32 partial tile -> out[z][M][N]
-template <int MODE>
-__global__ __launch_bounds__(kThreads, 1) void gemm_panel_kernel(const _Float16* __restrict__ A,
-                                                                const _Float16* __restrict__ W,
-                                                                const float* __restrict__ bias,
-                                                                void* __restrict__ out, int M, int N, int K,
-                                                                int kc) {
+// MODE 0: +bias -> fp16; 1: +bias, GELU -> fp16; 3: raw fp32 partial tile -> out[z][M][N].
+// TM = rows of A per workgroup: 64 (most workgroups, for tiny M) or 128 (halves the operand re-reads
+// and the workgroup count -- one wave of workgroups on 256 CUs for the 1024-token query batch).
+constexpr int kPanelThreads = 512;   // 8 waves: the LDS-DMA issue (1 KiB per wave-instruction) is the long
+                                      // pole of a one-shot panel fetch, so it is spread over more waves
+
+template <int MODE, int TM>
+__global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Float16* __restrict__ A,
+                                                                     const _Float16* __restrict__ W,
+                                                                     const float* __restrict__ bias,
+                                                                     void* __restrict__ out, int M, int N, int K,
+                                                                     int kc) {
+  constexpr int kTiles = (TM / 32) * (PN / 32);   // 32 x 32 output tiles: one per wave (8 or 4)
   extern __shared__ __attribute__((aligned(16))) char psm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * PM, n0 = blockIdx.x * PN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * PN;
   const int k0 = blockIdx.z * kc;
   const int cpr = kc >> 3;                 // 16-byte chunks per panel row (multiple of 16)
-  const int panel_chunks = PM * cpr;       // per operand
   char* sa = psm;
-  char* sw = psm + panel_chunks * 16;
+  char* sw = psm + TM * cpr * 16;
 
   // ---- one shot: every chunk of both panels (rows past M / N are clamped; their results are never
   // stored).  LDS position P = base + tid walks (row, chunk) incrementally: no divisions in the loop.
-  int row = tid / cpr, cp = tid - row * cpr;
-  const int drow = kThreads / cpr, dcp = kThreads - drow * cpr;
-  for (int base = 0; base < panel_chunks; base += kThreads) {
-    const int c = (cp & ~15) | ((cp ^ row) & 15);
-    const int ar = min(m0 + row, M - 1), wr = min(n0 + row, N - 1);
-    const _Float16* ga = A + (size_t)ar * K + k0 + c * 8;
-    const _Float16* gw = W + (size_t)wr * K + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(sa + (base + wave * 64) * 16), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)gw, (lptr_t)(sw + (base + wave * 64) * 16), 16, 0, 0);
-    row += drow;
-    cp += dcp;
-    if (cp >= cpr) { cp -= cpr; ++row; }
+  {
+    int row = tid / cpr, cp = tid - row * cpr;
+    const int drow = kPanelThreads / cpr, dcp = kPanelThreads - drow * cpr;
+    for (int base = 0; base < TM * cpr; base += kPanelThreads) {
+      const int c = (cp & ~15) | ((cp ^ row) & 15);
+      const _Float16* ga = A + (size_t)min(m0 + row, M - 1) * K + k0 + c * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(sa + (base + wave * 64) * 16), 16, 0, 0);
+      if (base < PN * cpr) {
+        const _Float16* gw = W + (size_t)min(n0 + row, N - 1) * K + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)gw, (lptr_t)(sw + (base + wave * 64) * 16), 16, 0, 0);
+      }
+      row += drow;
+      cp += dcp;
+      if (cp >= cpr) { cp -= cpr; ++row; }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (wave >= kTiles) return;   // TM = 64: waves 4..7 only helped fetching
 
   f32x16 acc;
 #pragma unroll
@@ -229,20 +238,29 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_panel_kernel(const _Float16*
   }
 }
 
-template <int MODE>
-int launch_panel(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
-                 int splitk, hipStream_t stream) {
+template <int MODE, int TM>
+int launch_panel_t(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
+                   int splitk, hipStream_t stream) {
   static bool attr_done = false;
-  const int lds = 2 * PM * kc * 2;
+  const int lds = (TM + PN) * kc * 2;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PM * PKC * 2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<MODE, TM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (TM + PN) * PKC * 2);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  dim3 grid((n + PN - 1) / PN, (m + PM - 1) / PM, splitk);
-  hipLaunchKernelGGL((gemm_panel_kernel<MODE>), grid, dim3(kThreads), lds, stream, a, w, bias, out, m, n, k, kc);
+  dim3 grid((n + PN - 1) / PN, (m + TM - 1) / TM, splitk);
+  hipLaunchKernelGGL((gemm_panel_kernel<MODE, TM>), grid, dim3(kPanelThreads), lds, stream, a, w, bias, out, m, n, k, kc);
   return (int)hipGetLastError();
+}
+
+// 128-row tiles once 64-row tiles would need more than one wave of workgroups on the chip
+template <int MODE>
+int launch_panel(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
+                 int splitk, hipStream_t stream) {
+  const long wgs64 = (long)((n + PN - 1) / PN) * ((m + 63) / 64) * splitk;
+  if (wgs64 > 256 && m > 64) return launch_panel_t<MODE, 128>(a, w, bias, out, m, n, k, kc, splitk, stream);
+  return launch_panel_t<MODE, 64>(a, w, bias, out, m, n, k, kc, splitk, stream);
 }
 
 }  // namespace

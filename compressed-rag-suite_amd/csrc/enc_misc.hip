@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
   ln_store<PL>(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
 }
 
-// y: [nsplit][tokens][hidden] fp32 split-K partial sums of the preceding GEMM (nsplit = 1: the full
-// product); bias / residual are added here when given, so the GEMM needs no epilogue pass.
-template <int PL>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ y, int nsplit,
+// y: [NS][tokens][hidden] fp32 split-K partial sums of the preceding GEMM (NS = 1: the full product);
+// bias / residual are added here when given, so the GEMM needs no epilogue pass.  NS is a template
+// parameter so that every partial-sum load of a row is in flight at once (a runtime loop made hipcc
+// wait for each split before issuing the next: one memory round trip per split).
+template <int PL, int NS>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ y,
                                                        const float* __restrict__ bias,
                                                        const float* residual,   // may alias x32 (in place)
                                                        const float* __restrict__ g,
@@ -79,18 +81,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   if (t >= tokens) return;
   const float* src = y + (size_t)t * hidden;
   const size_t split_stride = (size_t)tokens * hidden;
-  float v[PL];
+  float part[NS][PL], extra[2][PL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     const int c = lane + 64 * i;
-    float a = 0.f;
-    if (c < hidden) {
-      a = src[c];
-      for (int sidx = 1; sidx < nsplit; ++sidx) a += src[sidx * split_stride + c];
-      if (bias) a += bias[c];
-      if (residual) a += residual[(size_t)t * hidden + c];
-    }
-    v[i] = a;
+    const bool in = c < hidden;
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) part[sidx][i] = in ? src[sidx * split_stride + c] : 0.f;
+    extra[0][i] = (in && bias) ? bias[c] : 0.f;
+    extra[1][i] = (in && residual) ? residual[(size_t)t * hidden + c] : 0.f;
+  }
+  float v[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    float a = part[0][i];
+#pragma unroll
+    for (int sidx = 1; sidx < NS; ++sidx) a += part[sidx][i];
+    v[i] = (a + extra[0][i]) + extra[1][i];
   }
   ln_store<PL>(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
 }
@@ -162,10 +169,21 @@ int embed_ln_launch(const int* ids, const float* word, const float* pos, const f
 int layernorm_launch(const float* y, int nsplit, const float* bias, const float* residual, const float* g,
                      const float* b, float eps, int tokens, int hidden, float* x32, _Float16* x16,
                      hipStream_t stream) {
-#define CRS_LN(PL) hipLaunchKernelGGL((layernorm_kernel<PL>), dim3((tokens + 3) / 4), dim3(256), 0, stream, y, nsplit, \
-                                     bias, residual, g, b, eps, tokens, hidden, x32, x16)
-  if (hidden == 384) CRS_LN(6); else if (hidden == 768) CRS_LN(12); else if (hidden <= 64) CRS_LN(1); else CRS_LN(16);
+#define CRS_LN2(PL, NS) hipLaunchKernelGGL((layernorm_kernel<PL, NS>), dim3((tokens + 3) / 4), dim3(256), 0, stream, y, \
+                                         bias, residual, g, b, eps, tokens, hidden, x32, x16)
+#define CRS_LN(PL)                                                                    \
+  switch (nsplit) {                                                                   \
+    case 1: CRS_LN2(PL, 1); break;                                                    \
+    case 2: CRS_LN2(PL, 2); break;                                                    \
+    case 3: CRS_LN2(PL, 3); break;                                                    \
+    case 4: CRS_LN2(PL, 4); break;                                                    \
+    case 6: CRS_LN2(PL, 6); break;                                                    \
+    case 8: CRS_LN2(PL, 8); break;                                                    \
+    default: return -1;                                                               \
+  }
+  if (hidden == 384) { CRS_LN(6); } else if (hidden == 768) { CRS_LN(12); } else if (hidden <= 64) { CRS_LN(1); } else { CRS_LN(16); }
 #undef CRS_LN
+#undef CRS_LN2
   return (int)hipGetLastError();
 }
 
