@@ -100,14 +100,19 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
-    # ---- query encoder (architecture per BASELINE config, seeded random weights) + synthetic token ids
-    from oracle import encoder_ref as er   # weight/token GENERATORS only; nothing of the oracle is timed here
+    # ---- query encoder (architecture per BASELINE config, seeded random weights) + synthetic token ids.
+    # Everything in the timed path comes from the product package; oracle/ is imported further down,
+    # inside the cpu_baseline leg only.
     from rag._encoder import HipEncoder, ModelShape
-    cfg = er.MINILM_L6 if enc_name == "minilm" else er.BGE_BASE
-    enc_w = er.make_weights(cfg, seed=7)
-    enc = HipEncoder(ModelShape(cfg.vocab_size, cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, cfg.max_pos,
-                                cfg.ln_eps, cfg.pooling, cfg.max_seq), enc_w, device=dev)
-    ids_h, mask_h = er.synth_tokens(cfg, qb, QUERY_TOKENS, seed=4321 + rank, ragged=False)
+    from rag.embedding import _KNOWN, synthetic_weights
+    arch = _KNOWN["all-minilm-l6-v2" if enc_name == "minilm" else "bge-base-en-v1.5"]
+    shape = ModelShape(ln_eps=1e-12, **arch)
+    enc_w = synthetic_weights(shape, seed=7)
+    enc = HipEncoder(shape, enc_w, device=dev)
+    rng = np.random.default_rng(4321 + rank)
+    ids_h = rng.integers(1000, shape.vocab_size, size=(qb, QUERY_TOKENS)).astype(np.int32)
+    ids_h[:, 0], ids_h[:, -1] = 101, 102                      # [CLS] ... [SEP], no padding
+    mask_h = np.ones((qb, QUERY_TOKENS), dtype=np.int32)
     ids_d = torch.from_numpy(ids_h).to(dev)
     lens_d = torch.from_numpy(mask_h.sum(1).astype(np.int32)).to(dev)
     q32 = enc.forward(ids_d, lens_d).clone()
@@ -232,7 +237,9 @@ def main():
     cpu = None
     recall = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import scan_ref
+        from oracle import encoder_ref as er, scan_ref   # the CPU restatement: only ever the baseline / checker
+        cfg = er.EncoderConfig(shape.vocab_size, shape.hidden, shape.layers, shape.heads, shape.ffn, shape.max_pos, 2,
+                               shape.ln_eps, shape.max_seq, shape.pooling)
         sample_rows = min(rows, 200_000)
         slab_h = slab[:sample_rows, :dim].cpu().numpy()
         sc_h = scales[:sample_rows].cpu().numpy() if scales is not None else None

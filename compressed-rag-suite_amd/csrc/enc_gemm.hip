@@ -7,8 +7,9 @@
 // Both operands are K-contiguous, so a tile row is one 128-byte line: global loads are
 // 16 bytes/lane, 8 lanes per row, and the LDS image is XOR-swizzled by row
 // (chunk ^= (row >> 1) & 7) so every ds_read_b128 fragment read is bank-conflict free.
-// The next K-tile's global loads are issued before the current tile's MFMAs and written to the
-// other LDS buffer after them (one barrier per K-tile).
+// Staging is LDS-DMA (global_load_lds_dwordx4): the next K-tile is fetched into the other buffer
+// under the current tile's MFMAs, one vmcnt(0) + barrier per K-tile; the epilogue goes through
+// LDS so that global loads / stores are 16-byte coalesced rows.
 // Epilogues (fp32 accumulators -> ...):
 //   0  + bias                      -> fp16      (QKV projection)
 //   1  + bias, erf-GELU            -> fp16      (FFN up)
@@ -22,6 +23,7 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -44,6 +46,9 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {  // 128-byte rows, 
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int MODE>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* __restrict__ A,
                                                               const _Float16* __restrict__ W,
@@ -51,33 +56,30 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
                                                               const float* __restrict__ residual,
                                                               void* __restrict__ out, int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-  // staging: 4 A chunks + 4 W chunks per thread and K-tile
-  int g_row[4], g_chunk[4];
+  // staging by LDS-DMA: chunk P = j*256 + tid of a [128 rows][8 chunks] panel lands at LDS offset P*16
+  // (linear); the bank swizzle chunk ^= (row >> 1) & 7 is applied to the SOURCE column instead.
+  // Rows past M / N are clamped to the last valid row (their products are never stored).
+  const _Float16* ga[4];
+  const _Float16* gw[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int id = j * kThreads + tid;
-    g_row[j] = id >> 3;
-    g_chunk[j] = id & 7;
+    const int row = id >> 3, cp = id & 7;
+    const int c = cp ^ ((row >> 1) & 7);
+    ga[j] = A + (size_t)min(m0 + row, M - 1) * K + c * 8;
+    gw[j] = W + (size_t)min(n0 + row, N - 1) * K + c * 8;
   }
-  u32x4 ra[4], rw[4];
-  auto load_tile = [&](int k0) {
+  auto stage = [&](int buf, int k0) {
+    char* sa = smem + buf * kStageBytes + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int ar = m0 + g_row[j], wr = n0 + g_row[j];
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      ra[j] = (ar < M) ? *reinterpret_cast<const u32x4*>(A + (size_t)ar * K + k0 + g_chunk[j] * 8) : z;
-      rw[j] = (wr < N) ? *reinterpret_cast<const u32x4*>(W + (size_t)wr * K + k0 + g_chunk[j] * 8) : z;
-    }
-  };
-  auto park_tile = [&](char* st) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<u32x4*>(st + lds_off(g_row[j], g_chunk[j])) = ra[j];
-      *reinterpret_cast<u32x4*>(st + BM * 128 + lds_off(g_row[j], g_chunk[j])) = rw[j];
+      __builtin_amdgcn_global_load_lds((gptr_t)(ga[j] + k0), (lptr_t)(sa + j * (kThreads * 16)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gw[j] + k0), (lptr_t)(sa + BM * 128 + j * (kThreads * 16)), 16, 0, 0);
     }
   };
 
@@ -90,13 +92,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
-  load_tile(0);
-  park_tile(smem);
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
   for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool more = (k0 + BK) < K;
-    if (more) load_tile(k0 + BK);
+    if (k0 + BK < K) stage(cur ^ 1, k0 + BK);     // next tile in flight under this tile's MFMAs
     const char* sa = smem + cur * kStageBytes;
     const char* sw = sa + BM * 128;
 #pragma unroll
@@ -113,32 +114,62 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) park_tile(smem + (cur ^ 1) * kStageBytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
 
-  // epilogue: lane holds column (lane & 31), rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // ---- epilogue through LDS: accumulators -> fp32 tile [128][128] (the two staging buffers, 64 KiB),
+  // then each thread finishes 4 (fp32 out) or 8 (fp16 out) consecutive columns of a row with
+  // 16-byte coalesced loads / stores.  Lane holds column (lane & 31), rows (r&3) + 8(r>>2) + 4(lane>>5).
+  float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + fr;
-    if (col >= N) continue;
-    const float b = bias ? bias[col] : 0.f;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (row >= M) continue;
-        float v = acc[i][j][r] + b;
-        const size_t at = (size_t)row * N + col;
-        if (MODE == 1) v = gelu_erf(v);
-        if (MODE == 2) {
-          v += residual[at];
-          reinterpret_cast<float*>(out)[at] = v;
-        } else {
-          reinterpret_cast<_Float16*>(out)[at] = (_Float16)v;
-        }
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        tile[row * BN + wn * 64 + j * 32 + fr] = acc[i][j][r];
+      }
+  __syncthreads();
+  if (MODE == 2) {
+    float* o = reinterpret_cast<float*>(out);
+    for (int id = tid; id < BM * (BN / 4); id += kThreads) {
+      const int row = id / (BN / 4), c4 = (id % (BN / 4)) * 4;
+      const int gr = m0 + row, gc = n0 + c4;
+      if (gr >= M || gc >= N) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * BN + c4);
+      const size_t at = (size_t)gr * N + gc;
+      if (gc + 3 < N) {
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(residual + at);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b = *reinterpret_cast<const f32x4*>(bias + gc);
+        *reinterpret_cast<f32x4*>(o + at) = v + b + rs;
+      } else {
+        for (int e = 0; e < 4 && gc + e < N; ++e) o[at + e] = v[e] + (bias ? bias[gc + e] : 0.f) + residual[at + e];
+      }
+    }
+  } else {
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+    for (int id = tid; id < BM * (BN / 8); id += kThreads) {
+      const int row = id / (BN / 8), c8 = (id % (BN / 8)) * 8;
+      const int gr = m0 + row, gc = n0 + c8;
+      if (gr >= M || gc >= N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = tile[row * BN + c8 + e] + ((bias && gc + e < N) ? bias[gc + e] : 0.f);
+        v[e] = (MODE == 1) ? gelu_erf(x) : x;
+      }
+      const size_t at = (size_t)gr * N + gc;
+      if (gc + 7 < N) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+        *reinterpret_cast<f16x8*>(o + at) = h;
+      } else {
+        for (int e = 0; e < 8 && gc + e < N; ++e) o[at + e] = (_Float16)v[e];
       }
     }
   }
@@ -155,9 +186,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
 // by the LayerNorm kernel that follows anyway (enc_misc.hip), so no extra pass or atomics exist.
 // LDS image: rows of kc halves, 16-byte chunks XOR-swizzled by row inside each 256-byte group;
 // the DMA writes LDS linearly, so the swizzle is applied to the per-lane SOURCE address.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 constexpr int PN = 64, PKC = 384;
 
 // MODE 0: +bias -> fp16; 1: +bias, GELU -> fp16; 3: raw fp32 partial tile -> out[z][M][N].

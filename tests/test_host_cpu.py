@@ -192,3 +192,16 @@ def test_store_host_logic_shapes():
     assert meta == {"page_number": 2, "tokens": 1}
     with pytest.raises(ValueError):
         VectorStore({"index_dtype": "fp8"})
+
+
+def test_synthetic_weights_match_oracle_generator():
+    """The product's seeded checkpoint generator and the oracle's are the same streams (bench.py feeds
+    the product one to the GPU and the oracle restatement to the CPU baseline)."""
+    from oracle import encoder_ref as er
+    from rag._encoder import ModelShape
+    from rag.embedding import synthetic_weights
+    cfg = er.TINY
+    shape = ModelShape(cfg.vocab_size, cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, cfg.max_pos, cfg.ln_eps, cfg.pooling, cfg.max_seq)
+    a, b = synthetic_weights(shape, 5), er.make_weights(cfg, seed=5)
+    assert a.keys() == b.keys()
+    assert all(np.array_equal(a[k], b[k]) for k in a)
