@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="independent query batches in flight on separate HIP streams (1 GPU runs only)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the per-rank query batch size")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,6 +88,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     rows, dim, qb, k, slab_kind, enc_name = WORKLOADS[args.workload]
+    if args.queries > 0:
+        qb = args.queries
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
     pd = nat.padded_dim(dim, slab_type)
     id_base = rank * rows
@@ -160,13 +163,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Throughput mode (1 GPU): S independent batches in flight, each on its own stream with its own buffers,
-    # each step captured once into a hipGraph and replayed (the step is ~45 small launches).  With RCCL
-    # collectives in the step (N > 1) the steps run eagerly on one stream.
-    n_streams = max(1, args.streams) if world == 1 else 1
+    # Throughput mode: S independent batches in flight, each on its own stream with its own buffers; on
+    # one GPU each step is captured once into a hipGraph and replayed (the step is ~45 small launches).
+    # N > 1: the same S batches in flight, launched eagerly (the RCCL collectives of different batches
+    # are serialised on the process group's own stream; every rank issues them in the same order).
+    n_streams = max(1, args.streams)
     use_graph = (world == 1) and not args.no_graph
     ctxs = [Ctx() for _ in range(n_streams)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if world == 1 else [torch.cuda.current_stream()]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     graphs = []
     torch.cuda.synchronize()
     for c, st in zip(ctxs, streams):
@@ -186,11 +190,9 @@ def main():
             if use_graph:
                 with torch.cuda.stream(streams[sidx]):
                     graphs[sidx].replay()
-            elif world == 1:
+            else:
                 with torch.cuda.stream(streams[sidx]):
                     step(ctxs[sidx])
-            else:
-                step(ctxs[0])
 
     run(args.warmup)
     sync()

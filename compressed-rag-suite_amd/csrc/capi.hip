@@ -38,7 +38,7 @@ int device_cus() {
 
 
 struct Plan {
-  int pdim, tile_rows, n_tiles, nwg, kp;
+  int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
   size_t part_elems;  // nwg * nq * kp
 };
 
@@ -57,7 +57,11 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   p->tile_rows = slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
   const int cap = cus * crs::scan_wg_per_cu();
-  p->nwg = p->n_tiles < cap ? p->n_tiles : cap;
+  // all query blocks of a tile stream must be co-resident: streams = resident slots / query blocks
+  const int nqb = (nq + 63) / 64;
+  int streams = cap / nqb;
+  if (streams < 1) streams = 1;
+  p->nwg = p->n_tiles < streams ? p->n_tiles : streams;
   p->kp = partial_width(k);
   p->part_elems = (size_t)p->nwg * nq * p->kp;
   return CRS_OK;

@@ -76,7 +76,7 @@ struct WaveState {
     kq = lane >> 4;   // A/B: which 8-element k-quarter; D: which group of 4 rows
     sbuf = sbuf_all + wave * (L * 64);
     ibuf = ibuf_all + wave * (L * 64);
-    const int qi = blockIdx.y * 64 + wave * 16 + lr;
+    const int qi = CRS_QBLOCK * 64 + wave * 16 + lr;
     q_valid = qi < a.nq;
     const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
 #pragma unroll
@@ -119,6 +119,9 @@ struct WaveState {
           ++cnt;
         }
       }
+#ifdef CRS_EXPERIMENT_NO_COMPACT   /* timing-only build (tools/scan_probe): what would the kernel cost with selection for free? */
+      if (__any(cnt > L - 4)) { cnt = 0; tau = fmaxf(tau, 0.03f); }
+#else
       if (__any(cnt > L - 4)) {
 #ifdef CRS_STAMPS
         const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -129,12 +132,13 @@ struct WaveState {
         ++n_compact;
 #endif
       }
+#endif
     }
   }
 
   __device__ __forceinline__ void finish(const ScanArgs& a, int wave) {
-    const int qi = blockIdx.y * 64 + wave * 16 + lr;
-    const size_t o = ((size_t)(q_valid ? qi : 0) * gridDim.x + blockIdx.x) * a.kp;  // [nq, nwg, kp]
+    const int qi = CRS_QBLOCK * 64 + wave * 16 + lr;
+    const size_t o = ((size_t)(q_valid ? qi : 0) * CRS_NSTREAMS + CRS_STREAM) * a.kp;  // [nq, nwg, kp]
     flush_lists<L>(sbuf, ibuf, lane, cnt, tau, a.k, a.kp, a.part_scores + o, a.part_rows + o, q_valid);
   }
 };
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = gridDim.x;
-  const bool wave_active = (blockIdx.y * 64 + wave * 16) < a.nq;  // wave-uniform
+  const int nwg = CRS_NSTREAMS;
+  const bool wave_active = (CRS_QBLOCK * 64 + wave * 16) < a.nq;  // wave-uniform
 
   CRS_STAMP_REAL(62);
   CRS_STAMP(0);
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
   };
 
   // first tile's loads go out before the query fragments are fetched, so the two latencies overlap
-  int t = blockIdx.x;
+  int t = CRS_STREAM;
   load_tile(t);
   WaveState<D, TR, L> w;
   w.init(a, wave, lane, sbuf_all, ibuf_all);
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
   CRS_STAMP_REAL(63);
 #ifdef CRS_STAMPS
   if (a.stamps && (threadIdx.x & 63) == 0) {
-    a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + 60] = w.n_compact;
-    a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + 61] = w.cyc_compact;
+    a.stamps[((size_t)CRS_STREAM * 4 + (threadIdx.x >> 6)) * 64 + 60] = w.n_compact;
+    a.stamps[((size_t)CRS_STREAM * 4 + (threadIdx.x >> 6)) * 64 + 61] = w.cyc_compact;
   }
 #endif
 }
@@ -285,8 +289,8 @@ __global__ __launch_bounds__(kThreads, WGPC) void scan_f16_ring_kernel(const Sca
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = gridDim.x;
-  const bool wave_active = (blockIdx.y * 64 + wave * 16) < a.nq;
+  const int nwg = CRS_NSTREAMS;
+  const bool wave_active = (CRS_QBLOCK * 64 + wave * 16) < a.nq;
 
   // source offset (tile relative) of the 16-byte chunk that lands at LDS position P = j*256 + tid
   unsigned src_off[C::kLoads];
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(kThreads, WGPC) void scan_f16_ring_kernel(const Sca
     }
   };
 
-  int t = blockIdx.x;
+  int t = CRS_STREAM;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(t + s * nwg, s);
   WaveState<D, TR, L> w;
@@ -347,7 +351,7 @@ int launch_kernel(K kernel, int lds, const ScanArgs& a, int nwg, hipStream_t str
     if (e != hipSuccess) return (int)e;
     *attr_done = true;
   }
-  dim3 grid(nwg, (a.nq + 63) / 64);
+  dim3 grid((a.nq + 63) / 64, nwg);   // x = query block (fastest), y = tile stream
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, a);
   return (int)hipGetLastError();
 }

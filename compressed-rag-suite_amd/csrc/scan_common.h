@@ -7,6 +7,13 @@
 
 #include "scan.h"
 
+// Grid mapping: blockIdx.x = 64-query block, blockIdx.y = tile stream.  Workgroups that walk the SAME
+// tiles for different query blocks are adjacent in dispatch order and run in lockstep, so the tiles of
+// a stream are fetched from HBM once and re-read by the other query blocks from the Infinity Cache.
+#define CRS_QBLOCK ((int)blockIdx.x)
+#define CRS_STREAM ((int)blockIdx.y)
+#define CRS_NSTREAMS ((int)gridDim.y)
+
 namespace crs {
 namespace {
 
@@ -21,13 +28,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: u
   do {                                                                                           \
     if (a.stamps && (threadIdx.x & 63) == 0) {                                                   \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
-      a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (slot)] = t_;                \
+      a.stamps[((size_t)CRS_STREAM * 4 + (threadIdx.x >> 6)) * 64 + (slot)] = t_;                \
     }                                                                                            \
   } while (0)
 #define CRS_STAMP_REAL(slot)                                                                     \
   do {                                                                                           \
     if (a.stamps && (threadIdx.x & 63) == 0)                                                     \
-      a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+      a.stamps[((size_t)CRS_STREAM * 4 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define CRS_STAMP(slot) do {} while (0)

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kq = lane >> 4;
-  const int nwg = gridDim.x;
-  const bool wave_active = (blockIdx.y * 64 + wave * 16) < a.nq;
+  const int nwg = CRS_NSTREAMS;
+  const bool wave_active = (CRS_QBLOCK * 64 + wave * 16) < a.nq;
   float* sbuf = sbuf_all + wave * (L * 64);
   int* ibuf = ibuf_all + wave * (L * 64);
 
@@ -132,12 +132,12 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };
 
-  int t = blockIdx.x;
+  int t = CRS_STREAM;
   load_tile(t);
 
   // ---- this wave's queries -> 16-bit fixed point -> two int8 digit planes, resident in VGPRs.
   // B operand of v_mfma_i32_16x16x64_i8: lane holds query (lane & 15), k = 64 ks + 16 kq + j, j = 0..15.
-  const int qi = blockIdx.y * 64 + wave * 16 + lr;
+  const int qi = CRS_QBLOCK * 64 + wave * 16 + lr;
   const bool q_valid = qi < a.nq;
   const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 16;
   float amax = 0.f;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     cur ^= 1;
   }
   if (wave_active) {
-    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + blockIdx.x) * a.kp;  // [nq, nwg, kp]
+    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + CRS_STREAM) * a.kp;  // [nq, nwg, kp]
     flush_lists<L>(sbuf, ibuf, lane, cnt, tau, a.k, a.kp, a.part_scores + o, a.part_rows + o, q_valid);
   }
 }
@@ -247,7 +247,7 @@ int launch_i8(const ScanArgs& a, int nwg, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  dim3 grid(nwg, (a.nq + 63) / 64);
+  dim3 grid((a.nq + 63) / 64, nwg);   // x = query block (fastest), y = tile stream
   hipLaunchKernelGGL((scan_i8_kernel<D, TR, L>), grid, dim3(kThreads), C::kLds, stream, a);
   return (int)hipGetLastError();
 }
