@@ -79,13 +79,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     nat.require_gpu()
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CRS_DIST_BACKEND", "nccl")   # "gloo": functional rehearsal of N > 1 on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     rows, dim, qb, k, slab_kind, enc_name = WORKLOADS[args.workload]
     if args.queries > 0:
@@ -201,6 +206,35 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     res_i = ctxs[0].out_i
+    # functional check of the whole exchange (untimed): the final lists against a plain torch matmul + topk
+    # over every rank's shard, gathered and re-sorted -- catches any mix-up of query order, id bases,
+    # all-gather layout or merge
+    with torch.cuda.stream(streams[0]):
+        fin_s, fin_i = step(ctxs[0])
+    streams[0].synchronize()
+    q_chk = (nat.queries_to_f16(q32, slab_type) if world == 1 else ctxs[0].q_all).float()[:, :dim]
+    ref_s = torch.full((nq_all, k), float("-inf"), device=dev)
+    ref_i = torch.full((nq_all, k), -1, dtype=torch.int64, device=dev)
+    for lo in range(0, rows, 250_000):
+        blk = slab[lo:lo + 250_000, :dim].float()
+        if scales is not None:
+            blk = blk * scales[lo:lo + 250_000, None]
+        sc_blk = q_chk @ blk.T
+        ts, ti = sc_blk.topk(min(k, sc_blk.shape[1]), dim=1)
+        cat_s, cat_i = torch.cat([ref_s, ts], 1), torch.cat([ref_i, ti + lo + id_base], 1)
+        ref_s, pos = cat_s.topk(k, dim=1)
+        ref_i = torch.gather(cat_i, 1, pos)
+    if world > 1:
+        all_s = torch.empty((world * nq_all, k), device=dev); all_i = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_s, ref_s.contiguous()); dist.all_gather_into_tensor(all_i, ref_i.contiguous())
+        all_s = all_s.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)
+        all_i = all_i.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)
+        ref_s, pos = all_s.topk(k, dim=1)
+        ref_i = torch.gather(all_i, 1, pos)
+    tol = 2e-3 if slab_type == nat.SLAB_I8 else 2e-5     # int8: the kernel searches with 16-bit fixed-point queries
+    score_err = float((fin_s - ref_s).abs().max().item())
+    id_match = float((fin_i == ref_i).float().mean().item())
+    exchange_ok = bool(score_err < tol and id_match > 0.98)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -286,7 +320,7 @@ def main():
                        "queries_per_rank_per_step": qb, "queries_per_step": nq_all, "top_k": k,
                        "slab": slab_kind, "encoder_in_step": not args.scan_only,
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
-                       "query_tokens": QUERY_TOKENS, "streams_in_flight": n_streams, "hip_graph": use_graph,
+                       "query_tokens": QUERY_TOKENS, "streams_in_flight": n_streams, "hip_graph": use_graph, "exchange_check": {"ok": exchange_ok, "max_score_err": score_err, "id_match": round(id_match, 4)},
                        "index_build_s_per_gpu": round(t_build, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
