@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "scan.h"
@@ -143,6 +144,12 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.stamps = nullptr;
   a.tau_shared = share ? tau : nullptr;
   a.kp = p.kp;
+  {
+    static int boot = -1;
+    if (boot < 0) { const char* e = getenv("CRS_SCAN_BOOT"); boot = (e && e[0] == '0') ? 0 : 1; }
+    // short streams only: the bootstrap pays when a workgroup sees few tiles (see scan.hip)
+    a.boot = (boot && p.n_tiles / (p.nwg > 0 ? p.nwg : 1) < 24) ? 1 : 0;
+  }
   a.n_rows = (int)n_rows;
   a.n_tiles = p.n_tiles;
   a.nq = nq;

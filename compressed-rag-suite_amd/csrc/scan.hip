@@ -136,6 +136,51 @@ struct WaveState {
     }
   }
 
+  // ---- threshold bootstrap (k <= 16, TR == 32): the scores of a stream's first 64 rows stay in
+  // registers (16 per lane = exactly the input of kth_of_quad), the exact k-th best of those 64 rows
+  // becomes tau, and only rows >= tau are appended.  This replaces "append 64 unfiltered candidates
+  // per query, then run a full compaction over them" at the start of every stream.
+  float boot[16];
+
+  template <int STAGE>
+  __device__ __forceinline__ void tile_boot(const char* buf, int t, const ScanArgs& a) {
+    static_assert(C::kRt == 2, "bootstrap is written for 32-row tiles");
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::kKsteps; ++ks) {
+        const f16x8 af = *reinterpret_cast<const f16x8*>(
+            buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
+      }
+      const int row0 = t * TR + rt * 16 + kq * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) boot[STAGE * 8 + rt * 4 + i] = (row0 + i < a.n_rows) ? acc[i] : kNegInf;
+    }
+  }
+
+  // t0 / t1: the two tiles whose scores sit in boot[0..7] / boot[8..15]
+  __device__ __forceinline__ void boot_select(int t0, int t1, const ScanArgs& a) {
+    float s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = boot[j];
+    const float t = kth_of_quad(s, a.k);   // -inf while fewer than k valid rows were seen
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float sc = boot[j];
+      if (q_valid && sc >= t && sc > kNegInf) {
+        const int tile = (j < 8) ? t0 : t1;
+        sbuf[cnt * 64 + lane] = sc;
+        ibuf[cnt * 64 + lane] = tile * TR + ((j >> 2) & 1) * 16 + kq * 4 + (j & 3);
+        ++cnt;
+      }
+    }
+    if (q_valid) tau = fmaxf(tau, t);
+    // many ties on the threshold (e.g. duplicate rows) can leave a list too full for the next tile
+    if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0, tau_pub);
+  }
+
   __device__ __forceinline__ void finish(const ScanArgs& a, int wave) {
     const int qi = CRS_QBLOCK * 64 + wave * 16 + lr;
     const size_t o = ((size_t)(q_valid ? qi : 0) * CRS_NSTREAMS + CRS_STREAM) * a.kp;  // [nq, nwg, kp]
@@ -147,7 +192,11 @@ struct WaveState {
 // ASM_LOADS: issue the next tile's global loads through inline asm right at the top of the
 // iteration (hipcc otherwise sinks plain loads down to the ds_write that consumes them, which
 // serialises HBM latency with the math), and retire them with one hand-placed vmcnt(0).
-template <int D, int TR, int L, bool ASM_LOADS>
+// BOOT: peel the first two tiles of the stream and bootstrap the threshold from them in registers.
+// A separate instantiation (not a runtime flag): with the peeled code present hipcc schedules the
+// steady-state loop ~10 % slower (C4 177 -> 200 us), while short streams (C2, 6 tiles per workgroup)
+// gain 5 % from it; the launcher picks per launch.
+template <int D, int TR, int L, bool ASM_LOADS, bool BOOT>
 __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a) {
   using C = Cfg<D, TR, L>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,15 +227,16 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
 
   u32x4 st[C::kLoads];
   unsigned tg = 0;   // shared threshold fetched along with the next tile (ASM_LOADS only), applied one tile late
-  auto load_tile = [&](int tile) {
+  auto load_tile = [&](int tile_) {
+    const int tile = __builtin_amdgcn_readfirstlane(tile_);   // uniform by construction; make it provable
     if (tile < n_full) {
-      const char* base = slab + (size_t)tile * C::kTileBytes;  // uniform -> SGPR base + 32-bit lane offset
+      const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);  // SGPR base + 32-bit lane offset
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
         const unsigned off = (unsigned)(j * kThreads + tid) * 16u;
         if (ASM_LOADS) {
           u32x4 x;
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
+          asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
           st[j] = x;
         } else {
           st[j] = *reinterpret_cast<const u32x4*>(base + off);
@@ -242,6 +292,24 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
 
   int cur = 0;
   int it = 0;
+  if constexpr (BOOT && L == 16 && C::kRt == 2) {
+    if (t + nwg < a.n_tiles) {   // uniform: this stream has at least two tiles
+      const int t0 = t, t1 = t + nwg;
+      load_tile(t1);
+      if (wave_active) w.template tile_boot<0>(tile_buf, t0, a);
+      park_tile(tile_buf + C::kTileBytes);
+      __syncthreads();
+      load_tile(t1 + nwg);
+      if (wave_active) {
+        w.template tile_boot<1>(tile_buf + C::kTileBytes, t1, a);
+        w.boot_select(t0, t1, a);
+      }
+      park_tile(tile_buf);
+      __syncthreads();
+      t = t1 + nwg;
+      it = 2;
+    }
+  }
   for (; t < a.n_tiles; t += nwg) {
     load_tile(t + nwg);
     fetch_tau(w.tau_pub);
@@ -360,10 +428,13 @@ template <int D, int TR, int L>
 int launch_l(const ScanArgs& a, int nwg, hipStream_t stream) {
   using C = Cfg<D, TR, L>;
   constexpr int lists = 2 * C::kListBytes;
-  static bool done[4] = {false, false, false, false};
+  static bool done[5] = {false, false, false, false, false};
   switch (scan_variant()) {
-    case 0: return launch_kernel(&scan_f16_kernel<D, TR, L, false>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[0]);
-    case 3: return launch_kernel(&scan_f16_kernel<D, TR, L, true>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[3]);
+    case 0: return launch_kernel(&scan_f16_kernel<D, TR, L, false, false>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[0]);
+    case 3:
+      if (a.boot && L == 16 && TR == 32)
+        return launch_kernel(&scan_f16_kernel<D, TR, L, true, (L == 16 && TR == 32)>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[4]);
+      return launch_kernel(&scan_f16_kernel<D, TR, L, true, false>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[3]);
     case 2: return launch_kernel(&scan_f16_ring_kernel<D, TR, L, 2, 2>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[2]);
     default: {
       constexpr int NS = (L == 16) ? 4 : 3;

@@ -150,6 +150,19 @@ __device__ __forceinline__ float kth_of_quad(float (&s)[32], int k) {
   return __shfl(t, src);
 }
 
+// A pointer that IS wave-uniform (kernel argument + blockIdx arithmetic), made provably so for the
+// "s" (SGPR) operand of an inline-asm load: both halves go through v_readfirstlane.
+// HAZARD: an SGPR written by v_readfirstlane needs 5 wait states before a VMEM instruction may read
+// it as its base, and hipcc pads nothing inside an asm string -- every asm load that takes such a
+// pointer therefore opens with "s_nop 4" (cdna_hip_programming.md section 5.7 item 2).
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------- threshold sharing across workgroups
 // Every wave's tau is the k-th best of a SUBSET of the rows, hence a lower bound on the global k-th
 // best.  Waves publish it with an agent-scope atomic max on an order-preserving integer image of

@@ -72,20 +72,20 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   f32x4 sc_next[C::kRt], sc_cur[C::kRt];
   auto load_tile = [&](int tile) {
     if (tile < n_full) {
-      const char* base = slab + (size_t)tile * C::kTileBytes;
+      const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
         const unsigned off = (unsigned)(j * kThreads + tid) * 16u;
         u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
         st[j] = x;
       }
-      const float* sb = a.scales + (size_t)tile * TR;   // uniform base; this lane's rows 16 rt + 4 kq .. +3
+      const float* sb = uniform_ptr(a.scales + (size_t)tile * TR);   // this lane's rows 16 rt + 4 kq .. +3
 #pragma unroll
       for (int rt = 0; rt < C::kRt; ++rt) {
         const unsigned off = (unsigned)(rt * 16 + kq * 4) * 4u;
         f32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(sb) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(sb) : "memory");
         sc_next[rt] = x;
       }
     } else {

@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER, byref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcrs_hip.so")
+LIB_PATH = os.environ.get("CRS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libcrs_hip.so")  # override: A/B builds
 
 SLAB_F16 = 0
 SLAB_I8 = 1
