@@ -221,9 +221,35 @@ def main():
     gen_encoder("minilm", er.MINILM_L6, batch=3, seq=32, seed=12)
     gen_encoder("bge", er.BGE_BASE, batch=2, seq=16, seed=13)
     gen_scan()
+    gen_ir_metrics()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
+
+
+def gen_ir_metrics():
+    """tests/golden/ir_metrics.json: outputs of the reference's evaluation/retrieval/retrieval_metrics.py
+    (RetrievalMetrics static methods; loads standalone, numpy only) on seeded random rankings."""
+    import random
+    spec = importlib.util.spec_from_file_location("_ref_metrics", os.path.join(REF, "evaluation", "retrieval", "retrieval_metrics.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    R = m.RetrievalMetrics
+    rng = random.Random(7)
+    cases = []
+    for _ in range(60):
+        n_ret = rng.choice([0, 1, 3, 5, 10, 12])
+        retrieved = [f"chunk_{rng.randrange(30)}" for _ in range(n_ret)]
+        relevant = sorted({f"chunk_{rng.randrange(30)}" for _ in range(rng.choice([0, 1, 2, 5, 10]))})
+        row = {"retrieved": retrieved, "relevant": relevant, "mrr": R.mean_reciprocal_rank(retrieved, set(relevant)),
+               "ap": R.average_precision(retrieved, set(relevant))}
+        for k in (0, 1, 3, 5, 10):
+            row[f"p@{k}"] = R.precision_at_k(retrieved, set(relevant), k)
+            row[f"r@{k}"] = R.recall_at_k(retrieved, set(relevant), k)
+            row[f"f@{k}"] = R.f1_at_k(retrieved, set(relevant), k)
+        cases.append(row)
+    with open(os.path.join(OUT, "ir_metrics.json"), "w") as fh:
+        json.dump(cases, fh)
 
 if __name__ == "__main__":
     main()

@@ -205,3 +205,20 @@ def test_synthetic_weights_match_oracle_generator():
     a, b = synthetic_weights(shape, 5), er.make_weights(cfg, seed=5)
     assert a.keys() == b.keys()
     assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_ir_metrics_match_reference_golden():
+    from rag import ir_eval
+    with open(os.path.join(ROOT, "tests", "golden", "ir_metrics.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) == 60
+    for c in cases:
+        ret, rel = c["retrieved"], set(c["relevant"])
+        assert ir_eval.mean_reciprocal_rank(ret, rel) == c["mrr"]
+        assert ir_eval.average_precision(ret, rel) == c["ap"]
+        for k in (0, 1, 3, 5, 10):
+            assert ir_eval.precision_at_k(ret, rel, k) == c[f"p@{k}"]
+            assert ir_eval.recall_at_k(ret, rel, k) == c[f"r@{k}"]
+            assert ir_eval.f1_at_k(ret, rel, k) == c[f"f@{k}"]
+    agg = ir_eval.evaluate_rankings([c["retrieved"] for c in cases], [set(c["relevant"]) for c in cases], ks=(1, 10))
+    assert abs(agg["mrr"] - sum(c["mrr"] for c in cases) / 60) < 1e-12 and "f1@10" in agg

@@ -159,3 +159,10 @@ def test_pipeline_end_to_end_vs_oracle(cuda):
         assert pipe.retrieve_batch([query])[0] == got
     stats = pipe.get_stats()
     assert stats["embedding_dim"] == 384 and stats["retrieval"]["distance_metric"] == "cosine"
+    # batched IR evaluation (fills the fields the reference's results leave null), relevance = oracle top-3
+    from rag import ir_eval
+    qs = ["how does quantization affect perplexity", "what stores the embeddings"]
+    rel = [{c["chunk_id"] for c in rr.retrieve(q, search=ref.search, embed=oracle_embed, top_k=3, similarity_threshold=0.0,
+                                               do_rerank=True, diversity_penalty=0.1)} for q in qs]
+    res = ir_eval.evaluate_pipeline(pipe, qs, rel, ks=(1, 3))
+    assert res["recall@3"] == 1.0 and res["precision@3"] == 1.0 and res["mrr"] == 1.0 and res["num_questions"] == 2
