@@ -102,9 +102,29 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   if (tid == 0) sh_cnt = 0;
   for (int r = tid; r < k_out; r += kThreads) { os[r] = kNegInf; oi[r] = -1; }
 
-  // 1. bucket maxima
+  // Fast path (a query's lists contiguous, m <= 8192: every stage-2 merge of the scan): each thread
+  // pulls its <= 32 strided candidates into registers with all loads in flight at once, so the
+  // candidate set crosses the memory system exactly once (the generic path below walks it twice in
+  // batches of 8 and was bound by those serial round trips).
+  constexpr int kRegE = 32;
+  const bool cached = contig && m <= kRegE * kThreads;
+  float cs[kRegE];
+  IdT ci[kRegE];
   float best = kNegInf;
-  CRS_FOR_EACH_ENTRY({ best = fmaxf(best, (id >= 0) ? s : kNegInf); })
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < kRegE; ++u) {
+      const int e = tid + u * kThreads;
+      const bool in = e < m;
+      cs[u] = in ? qs[e] : kNegInf;
+      ci[u] = in ? qi[e] : (IdT)-1;
+    }
+#pragma unroll
+    for (int u = 0; u < kRegE; ++u) best = fmaxf(best, (ci[u] >= 0) ? cs[u] : kNegInf);
+  } else {
+    // 1. bucket maxima
+    CRS_FOR_EACH_ENTRY({ best = fmaxf(best, (id >= 0) ? s : kNegInf); })
+  }
   // 2. k-th largest of the 256 maxima (k_out <= 64)
   const float sorted = wave_sort_desc(best, lane);
   sh_sorted[wave][lane] = sorted;
@@ -118,12 +138,22 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   const float tau = __shfl(t, k_out - 1);
 
   // 3. candidates >= tau
-  CRS_FOR_EACH_ENTRY({
-    if (id >= 0 && s >= tau) {
-      const int p = atomicAdd(&sh_cnt, 1);
-      if (p < kCap) { sh_cs[p] = s; sh_ci[p] = id; }
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < kRegE; ++u) {
+      if (ci[u] >= 0 && cs[u] >= tau) {
+        const int p = atomicAdd(&sh_cnt, 1);
+        if (p < kCap) { sh_cs[p] = cs[u]; sh_ci[p] = ci[u]; }
+      }
     }
-  })
+  } else {
+    CRS_FOR_EACH_ENTRY({
+      if (id >= 0 && s >= tau) {
+        const int p = atomicAdd(&sh_cnt, 1);
+        if (p < kCap) { sh_cs[p] = s; sh_ci[p] = id; }
+      }
+    })
+  }
   __syncthreads();
   const int cnt = sh_cnt;
   if (cnt <= kCap) {
