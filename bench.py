@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--scan-only", action="store_true", help="diagnostic: skip the encoder (NOT the metric)")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=16,
                     help="independent query batches in flight on separate HIP streams (1 GPU runs only)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the per-rank query batch size")
