@@ -147,6 +147,11 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   {
     static int boot = -1;
     if (boot < 0) { const char* e = getenv("CRS_SCAN_BOOT"); boot = (e && e[0] == '0') ? 0 : 1; }
+    {
+      static int sched = -1;
+      if (sched < 0) { const char* e = getenv("CRS_SCAN_SCHED"); sched = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+      a.sched = sched;
+    }
     // short streams only: the bootstrap pays when a workgroup sees few tiles (see scan.hip)
     a.boot = (boot && p.n_tiles / (p.nwg > 0 ? p.nwg : 1) < 24) ? 1 : 0;
   }

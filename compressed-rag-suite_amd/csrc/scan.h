@@ -17,6 +17,7 @@ struct ScanArgs {
   int n_tiles;
   int nq;
   int k;
+  int sched;              // synchronous-compaction schedule: 0 none, 1 {3,4,6,8,12,...}, 2 {4,8,16,...}
   int boot;               // 1: bootstrap the threshold from the first 64 rows in registers (scan.hip)
   int kp;                 // slots per (query, workgroup) partial list: >= k (16 when k <= 16)
 };

@@ -98,6 +98,9 @@ struct WaveState {
     tau_pub = (a.tau_shared && q_valid) ? a.tau_shared + qi : nullptr;
   }
 
+  // CHECK = false: the caller keeps every list at <= L - 4*kRt entries at tile boundaries (workgroup-
+  // synchronous compaction, variant A), so no list can overflow inside a tile and no check is needed.
+  template <bool CHECK = true>
   __device__ __forceinline__ void tile(const char* buf, int t, const ScanArgs& a) {
 #pragma unroll
     for (int rt = 0; rt < C::kRt; ++rt) {
@@ -122,7 +125,7 @@ struct WaveState {
 #ifdef CRS_EXPERIMENT_NO_COMPACT   /* timing-only build (tools/scan_probe): what would the kernel cost with selection for free? */
       if (__any(cnt > L - 4)) { cnt = 0; tau = fmaxf(tau, 0.03f); }
 #else
-      if (__any(cnt > L - 4)) {
+      if (CHECK && __any(cnt > L - 4)) {
 #ifdef CRS_STAMPS
         const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -134,6 +137,25 @@ struct WaveState {
       }
 #endif
     }
+  }
+
+  // ---- compaction on demand (variant A calls it on a fixed schedule so that the four waves of a
+  // workgroup compact in the SAME tile: with the per-tile barrier, four waves compacting in four
+  // different tiles stall the workgroup four times -- the slowest workgroups of a C2 launch spent
+  // 16-19 k of their 68 k cycles at barriers waiting for a sibling's compaction).
+  __device__ __forceinline__ void compact_now(const ScanArgs& a) {
+#ifdef CRS_STAMPS
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef CRS_EXPERIMENT_NO_COMPACT
+    cnt = 0; tau = fmaxf(tau, 0.03f);
+#else
+    compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0, tau_pub);
+#endif
+#ifdef CRS_STAMPS
+    cyc_compact += __builtin_amdgcn_s_memtime() - t0_;
+    ++n_compact;
+#endif
   }
 
   // ---- threshold bootstrap (k <= 16, TR == 32): the scores of a stream's first 64 rows stay in
@@ -178,7 +200,7 @@ struct WaveState {
     }
     if (q_valid) tau = fmaxf(tau, t);
     // many ties on the threshold (e.g. duplicate rows) can leave a list too full for the next tile
-    if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0, tau_pub);
+    if (__any(cnt > L - 4 * C::kRt)) compact_now(a);
   }
 
   __device__ __forceinline__ void finish(const ScanArgs& a, int wave) {
@@ -292,6 +314,18 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
 
   int cur = 0;
   int it = 0;
+  // Workgroup-synchronous compaction by SCHEDULE: every wave compacts at the same tile counts
+  // (3, 4, 6, 8, 12, 16, 24, 32, ... : between two of them a query gains ~k new candidates), so the
+  // four compactions of a workgroup overlap in time instead of stalling the per-tile barrier one
+  // after the other.  No communication is needed (the LDS budget of 2 workgroups / CU is used to the
+  // byte); the in-tile overflow check stays as a safety net for outlier lanes.
+  const int sched = a.sched;
+  auto scheduled = [sched](int n) {
+    if (sched == 0 || n < 3) return false;
+    const bool pow2 = (n & (n - 1)) == 0;
+    if (sched == 2) return pow2;
+    return pow2 || ((n % 3) == 0 && ((n / 3) & (n / 3 - 1)) == 0);
+  };
   if constexpr (BOOT && L == 16 && C::kRt == 2) {
     if (t + nwg < a.n_tiles) {   // uniform: this stream has at least two tiles
       const int t0 = t, t1 = t + nwg;
@@ -313,7 +347,10 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
   for (; t < a.n_tiles; t += nwg) {
     load_tile(t + nwg);
     fetch_tau(w.tau_pub);
-    if (wave_active) w.tile(tile_buf + cur * C::kTileBytes, t, a);
+    if (wave_active) {
+      if (scheduled(it)) w.compact_now(a);
+      w.template tile<true>(tile_buf + cur * C::kTileBytes, t, a);
+    }
     if (it < 14) CRS_STAMP(3 + 3 * it);
     park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
     if (ASM_LOADS && w.tau_pub) w.tau = fmaxf(w.tau, foreign_tau(tg));

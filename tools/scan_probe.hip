@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   unsigned* tau; hipMalloc(&tau, nq * 4);
   crs::ScanArgs a{};
   a.q = q; a.slab = slab; a.scales = nullptr; a.part_scores = ps; a.part_rows = pr; a.tau_shared = crs::scan_share_tau() ? tau : nullptr;
-  a.stamps = st; a.n_rows = rows; a.n_tiles = n_tiles; a.nq = nq; a.k = k; a.kp = k; a.boot = getenv("CRS_SCAN_BOOT") && getenv("CRS_SCAN_BOOT")[0] == '0' ? 0 : 1;
+  a.stamps = st; a.n_rows = rows; a.n_tiles = n_tiles; a.nq = nq; a.k = k; a.kp = k; a.sched = getenv("CRS_SCAN_SCHED") ? atoi(getenv("CRS_SCAN_SCHED")) : 1; a.boot = getenv("CRS_SCAN_BOOT") && getenv("CRS_SCAN_BOOT")[0] == '0' ? 0 : 1;
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(st, 0, (size_t)nwg * 4 * 64 * 8);
     hipMemset(tau, 0, nq * 4);
@@ -67,6 +67,24 @@ int main(int argc, char** argv) {
   }
   pr2("final compaction+store", 58, 59);
   pr2("whole kernel (0->59)", 0, 59);
+  {
+    // the slowest workgroups (wave 0 of each): what did they do differently?
+    std::vector<std::pair<double,int>> order;
+    for (int b = 0; b < nwg; ++b) order.push_back({(double)(hs[((size_t)b * 4) * 64 + 59] - hs[((size_t)b * 4) * 64 + 0]), b});
+    std::sort(order.begin(), order.end());
+    auto show = [&](int b) {
+      const unsigned long long* r = &hs[((size_t)b * 4) * 64];
+      int tiles = 0; for (int it = 0; it < 14; ++it) if (r[3 + 3 * it]) ++tiles;
+      printf("    wg %4d  total %7.0f  start+%5.0f ns  qfrag %6.0f  tiles(stamped) %2d  compactions %llu (%6llu cyc)  final %6.0f  wait/park sum %6.0f  barrier sum %6.0f\n", b,
+             (double)(r[59] - r[0]), (double)(r[62] - (unsigned long long)t0) * 10.0, (double)(r[1] - r[0]), tiles, r[60], r[61], (double)(r[59] - r[58]),
+             [&]{ double s_ = 0; for (int it = 0; it < 14; ++it) if (r[4 + 3 * it]) s_ += (double)(r[4 + 3 * it] - r[3 + 3 * it]); return s_; }(),
+             [&]{ double s_ = 0; for (int it = 0; it < 14; ++it) if (r[5 + 3 * it]) s_ += (double)(r[5 + 3 * it] - r[4 + 3 * it]); return s_; }());
+    };
+    printf("  fastest 4 / median 2 / slowest 8 workgroups:\n");
+    for (int i = 0; i < 4; ++i) show(order[i].second);
+    show(order[nwg / 2].second); show(order[nwg / 2 + 1].second);
+    for (int i = nwg - 8; i < nwg; ++i) show(order[i].second);
+  }
   printf("  compactions per wave: median %.0f max %.0f ; cycles in compaction: median %.0f max %.0f\n", med(col(60)), mx(col(60)), med(col(61)), mx(col(61)));
   return 0;
 }
