@@ -140,43 +140,61 @@ def main():
         """Buffers of one in-flight query batch (a step touches nothing outside its Ctx + read-only state)."""
         def __init__(self):
             self.q_out = torch.empty((qb, dim), dtype=torch.float32, device=dev)
+            self.q16 = torch.empty((qb, pd), dtype=torch.float16, device=dev)
             self.enc_ws = torch.empty(enc.workspace_bytes(qb, QUERY_TOKENS), dtype=torch.uint8, device=dev)
             self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k, rows), dtype=torch.uint8, device=dev)
             self.out_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
             self.out_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
+            self.graphs = None
             if world > 1:
                 self.q_all = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
                 self.gs = torch.empty((world * nq_all, k), dtype=torch.float32, device=dev)
                 self.gi = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
+                self.fin_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
+                self.fin_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
+
+    # The step is three device segments with the two exchanges between them; every segment reads and
+    # writes fixed buffers of its Ctx, so each can be captured once into a hipGraph and replayed.
+    def seg_encode(c):      # token ids -> fp16 queries of this rank
+        q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws)
+        nat.queries_to_f16(q, slab_type, out=c.q16)
+
+    def seg_scan(c):        # all queries of the step x this rank's shard -> per-shard top-k
+        nat.cosine_topk(c.q_all if world > 1 else c.q16, slab, rows, dim, k, slab_type=slab_type, scales=scales,
+                        id_base=id_base, workspace=c.ws, out_scores=c.out_s, out_ids=c.out_i)
+
+    def seg_merge(c):       # N > 1: the gathered per-shard lists -> global top-k
+        nat.merge_topk(c.gs.view(world, nq_all, k), c.gi.view(world, nq_all, k), k, out_scores=c.fin_s, out_ids=c.fin_i)
+
+    segs = (seg_encode, seg_scan) + ((seg_merge,) if world > 1 else ())
 
     def step(c):
-        q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws)
-        q16 = nat.queries_to_f16(q, slab_type)
+        run_seg = (lambda j: c.graphs[j].replay()) if c.graphs is not None else (lambda j: segs[j](c))
+        run_seg(0)
         if world > 1:
-            dist.all_gather_into_tensor(c.q_all, q16)
-            q16 = c.q_all
-        s, i = nat.cosine_topk(q16, slab, rows, dim, k, slab_type=slab_type, scales=scales, id_base=id_base,
-                               workspace=c.ws, out_scores=c.out_s, out_ids=c.out_i)
+            dist.all_gather_into_tensor(c.q_all, c.q16)
+        run_seg(1)
         if world > 1:
-            dist.all_gather_into_tensor(c.gs, s)
-            dist.all_gather_into_tensor(c.gi, i)
-            s, i = nat.merge_topk(c.gs.view(world, nq_all, k), c.gi.view(world, nq_all, k), k)
-        return s, i
+            dist.all_gather_into_tensor(c.gs, c.out_s)
+            dist.all_gather_into_tensor(c.gi, c.out_i)
+            run_seg(2)
+            return c.fin_s, c.fin_i
+        return c.out_s, c.out_i
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Throughput mode: S independent batches in flight, each on its own stream with its own buffers; on
-    # one GPU each step is captured once into a hipGraph and replayed (the step is ~45 small launches).
-    # N > 1: the same S batches in flight, launched eagerly (the RCCL collectives of different batches
-    # are serialised on the process group's own stream; every rank issues them in the same order).
+    # Throughput mode: S independent batches in flight, each on its own stream with its own buffers.  The
+    # device segments of a step (~45 small launches) are captured once per batch into hipGraphs and
+    # replayed; for N > 1 the RCCL collectives between the segments are launched eagerly (those of
+    # different batches are serialised on the process group's own stream; every rank issues them in the
+    # same order).
     n_streams = max(1, args.streams)
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     ctxs = [Ctx() for _ in range(n_streams)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    graphs = []
     torch.cuda.synchronize()
     for c, st in zip(ctxs, streams):
         with torch.cuda.stream(st):
@@ -184,20 +202,20 @@ def main():
                 step(c)
         st.synchronize()
         if use_graph:
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_, stream=st):
-                step(c)
-            graphs.append(g_)
+            gl = []
+            for seg in segs:
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=st):
+                    seg(c)
+                gl.append(g_)
+            c.graphs = gl
+    sync()
 
     def run(n):
         for it in range(n):
             sidx = it % n_streams
-            if use_graph:
-                with torch.cuda.stream(streams[sidx]):
-                    graphs[sidx].replay()
-            else:
-                with torch.cuda.stream(streams[sidx]):
-                    step(ctxs[sidx])
+            with torch.cuda.stream(streams[sidx]):
+                step(ctxs[sidx])
 
     run(args.warmup)
     sync()

@@ -62,7 +62,9 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   const int nqb = (nq + 63) / 64;
   int streams = cap / nqb;
   if (streams < 1) streams = 1;
+  if (nqb > 1 && streams >= 8) streams &= ~7;   // whole rounds over the 8 XCDs (scan_common.h: grid mapping)
   p->nwg = p->n_tiles < streams ? p->n_tiles : streams;
+  if (nqb > 1 && p->nwg >= 8) p->nwg &= ~7;
   p->kp = partial_width(k);
   p->part_elems = (size_t)p->nwg * nq * p->kp;
   return CRS_OK;
@@ -159,6 +161,8 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.n_tiles = p.n_tiles;
   a.nq = nq;
   a.k = k;
+  a.nwg = p.nwg;
+  a.nqb = (nq + 63) / 64;
   const int e = (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
                                            : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
   *ps_out = ps;

@@ -20,6 +20,8 @@ struct ScanArgs {
   int sched;              // synchronous-compaction schedule: 0 none, 1 {3,4,6,8,12,...}, 2 {4,8,16,...}
   int boot;               // 1: bootstrap the threshold from the first 64 rows in registers (scan.hip)
   int kp;                 // slots per (query, workgroup) partial list: >= k (16 when k <= 16)
+  int nwg;                // tile streams (workgroups per query block)
+  int nqb;                // 64-query blocks; the grid is nqb * nwg workgroups (scan_common.h: grid mapping)
 };
 
 int scan_tile_rows(int pdim);

@@ -456,7 +456,7 @@ int launch_kernel(K kernel, int lds, const ScanArgs& a, int nwg, hipStream_t str
     if (e != hipSuccess) return (int)e;
     *attr_done = true;
   }
-  dim3 grid((a.nq + 63) / 64, nwg);   // x = query block (fastest), y = tile stream
+  dim3 grid(a.nqb * a.nwg);           // 1-D; (query block, tile stream) from scan_common.h's grid mapping
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, a);
   return (int)hipGetLastError();
 }

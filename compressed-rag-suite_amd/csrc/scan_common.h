@@ -7,12 +7,16 @@
 
 #include "scan.h"
 
-// Grid mapping: blockIdx.x = 64-query block, blockIdx.y = tile stream.  Workgroups that walk the SAME
-// tiles for different query blocks are adjacent in dispatch order and run in lockstep, so the tiles of
-// a stream are fetched from HBM once and re-read by the other query blocks from the Infinity Cache.
-#define CRS_QBLOCK ((int)blockIdx.x)
-#define CRS_STREAM ((int)blockIdx.y)
-#define CRS_NSTREAMS ((int)gridDim.y)
+// Grid mapping (1-D grid of nqb * nwg workgroups): every tile stream is walked by nqb workgroups, one per
+// 64-query block.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), and each
+// XCD has its own L2: the nqb workgroups of a stream are therefore placed on linear ids b, b+8, b+16, ...
+// so that they share an XCD, start together and run in lockstep -- the stream's tiles are then fetched
+// from HBM once and re-read by the other query blocks from that XCD's L2 (with the natural order
+// b = stream * nqb + qblock the re-reads come from four different XCDs and are served by the Infinity
+// Cache at ~8 TB/s, which bounded the 256-query C3 launch).  Placement is only a speed matter.
+#define CRS_NSTREAMS (a.nwg)
+#define CRS_QBLOCK (crs::grid_qblock(a))
+#define CRS_STREAM (crs::grid_stream(a))
 
 namespace crs {
 namespace {
@@ -20,6 +24,19 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: usable as an asm operand
+
+__device__ __forceinline__ int grid_qblock(const ScanArgs& a) {
+  const int b = (int)blockIdx.x;
+  if (a.nqb == 1) return 0;
+  if (a.nwg & 7) return b % a.nqb;
+  return (b >> 3) % a.nqb;
+}
+__device__ __forceinline__ int grid_stream(const ScanArgs& a) {
+  const int b = (int)blockIdx.x;
+  if (a.nqb == 1) return b;
+  if (a.nwg & 7) return b / a.nqb;
+  return ((b >> 3) / a.nqb) * 8 + (b & 7);
+}
 
 
 // In-kernel timeline stamps for tools/scan_probe.hip (a separate diagnostic build); no code in the product build.

@@ -247,7 +247,7 @@ int launch_i8(const ScanArgs& a, int nwg, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  dim3 grid((a.nq + 63) / 64, nwg);   // x = query block (fastest), y = tile stream
+  dim3 grid(a.nqb * a.nwg);           // 1-D; (query block, tile stream) from scan_common.h's grid mapping
   hipLaunchKernelGGL((scan_i8_kernel<D, TR, L>), grid, dim3(kThreads), C::kLds, stream, a);
   return (int)hipGetLastError();
 }

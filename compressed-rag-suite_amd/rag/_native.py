@@ -111,10 +111,11 @@ def slab_append_f32(emb, slab, row0: int, slab_type: int, scales=None, shadow=No
                                      _ptr(shadow), row0, _stream_ptr()))
 
 
-def queries_to_f16(q32, slab_type: int = SLAB_F16):
+def queries_to_f16(q32, slab_type: int = SLAB_F16, out=None):
     import torch
     nq, dim = q32.shape
-    out = torch.empty((nq, padded_dim(dim, slab_type)), dtype=torch.float16, device=q32.device)
+    if out is None:
+        out = torch.empty((nq, padded_dim(dim, slab_type)), dtype=torch.float16, device=q32.device)
     check(load().crs_queries_to_f16(_ptr(q32), nq, dim, slab_type, _ptr(out), _stream_ptr()))
     return out
 
@@ -143,12 +144,12 @@ def cosine_topk(q16, slab, n_rows: int, dim: int, k: int, *, slab_type: int = SL
     return out_scores, out_ids
 
 
-def merge_topk(scores, ids, k_out: int):
+def merge_topk(scores, ids, k_out: int, out_scores=None, out_ids=None):
     """scores/ids: cuda [G, nq, k_in] (fp32 / int64) -> global top-k_out per query."""
     import torch
     g, nq, k_in = scores.shape
-    out_s = torch.empty((nq, k_out), dtype=torch.float32, device=scores.device)
-    out_i = torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
+    out_s = out_scores if out_scores is not None else torch.empty((nq, k_out), dtype=torch.float32, device=scores.device)
+    out_i = out_ids if out_ids is not None else torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
     check(load().crs_merge_topk(_ptr(scores), _ptr(ids), g, nq, k_in, k_out, _ptr(out_s), _ptr(out_i),
                                 _stream_ptr()))
     return out_s, out_i

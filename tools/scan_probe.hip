@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   unsigned* tau; hipMalloc(&tau, nq * 4);
   crs::ScanArgs a{};
   a.q = q; a.slab = slab; a.scales = nullptr; a.part_scores = ps; a.part_rows = pr; a.tau_shared = crs::scan_share_tau() ? tau : nullptr;
-  a.stamps = st; a.n_rows = rows; a.n_tiles = n_tiles; a.nq = nq; a.k = k; a.kp = k; a.sched = getenv("CRS_SCAN_SCHED") ? atoi(getenv("CRS_SCAN_SCHED")) : 1; a.boot = getenv("CRS_SCAN_BOOT") && getenv("CRS_SCAN_BOOT")[0] == '0' ? 0 : 1;
+  a.stamps = st; a.n_rows = rows; a.n_tiles = n_tiles; a.nq = nq; a.k = k; a.nqb = (nq + 63) / 64; a.nwg = nwg; a.kp = k; a.sched = getenv("CRS_SCAN_SCHED") ? atoi(getenv("CRS_SCAN_SCHED")) : 1; a.boot = getenv("CRS_SCAN_BOOT") && getenv("CRS_SCAN_BOOT")[0] == '0' ? 0 : 1;
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(st, 0, (size_t)nwg * 4 * 64 * 8);
     hipMemset(tau, 0, nq * 4);
