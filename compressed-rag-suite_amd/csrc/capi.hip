@@ -40,6 +40,8 @@ int device_cus() {
 
 struct Plan {
   int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
+  int nqb;                                 // query blocks (64 queries each; 32 * wide_nw for the wide kernel)
+  int wide_nw;                             // > 0: scan_wide.hip with this many waves per workgroup
   size_t part_elems;  // nwg * nq * kp
 };
 
@@ -55,11 +57,14 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   const int cus = device_cus();
   if (cus <= 0) return fail(CRS_EHIP, "no HIP device available%s");
   p->pdim = crs_row_elems(dim, slab_type);
-  p->tile_rows = slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
+  p->wide_nw = slab_type == CRS_SLAB_F16 ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
+  p->tile_rows = p->wide_nw ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
-  const int cap = cus * crs::scan_wg_per_cu();
+  const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim) : crs::scan_wg_per_cu());
   // all query blocks of a tile stream must be co-resident: streams = resident slots / query blocks
-  const int nqb = (nq + 63) / 64;
+  const int qpb = p->wide_nw ? 32 * p->wide_nw : 64;
+  const int nqb = (nq + qpb - 1) / qpb;
+  p->nqb = nqb;
   int streams = cap / nqb;
   if (streams < 1) streams = 1;
   if (nqb > 1 && streams >= 8) streams &= ~7;   // whole rounds over the 8 XCDs (scan_common.h: grid mapping)
@@ -162,9 +167,10 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.nq = nq;
   a.k = k;
   a.nwg = p.nwg;
-  a.nqb = (nq + 63) / 64;
-  const int e = (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
-                                           : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
+  a.nqb = p.nqb;
+  const int e = p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
+                : (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
+                                             : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
   *ps_out = ps;
   *pr_out = pr;
   return e;

@@ -31,6 +31,10 @@ bool scan_share_tau();  // CRS_SCAN_SHARE_TAU=0 disables cross-workgroup thresho
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
 int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
+// scan_wide.hip: 65+ queries per launch, k <= 16, fp16 slabs
+int scan_wide_waves(int nq, int k, int pdim);
+int scan_wide_wg_per_cu(int nw, int pdim);
+int scan_launch_wide(const ScanArgs& a, int pdim, int nw, hipStream_t stream);
 
 // merge.hip
 int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,
