@@ -42,6 +42,7 @@ struct Plan {
   int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
   int nqb;                                 // query blocks (64 queries each; 32 * wide_nw for the wide kernel)
   int wide_nw;                             // > 0: scan_wide.hip with this many waves per workgroup
+  int group_best;                          // 1: the scan leaves tile representatives (scan_refine.hip finishes)
   size_t part_elems;  // nwg * nq * kp
 };
 
@@ -49,6 +50,17 @@ struct Plan {
 // dumped unselected)
 int partial_width(int k) { return (crs::scan_share_tau() && k <= 16) ? 16 : k; }
 size_t tau_bytes(int nq) { return align_up16((size_t)nq * 4); }
+
+bool dump_enabled() {   // CRS_SCAN_DUMP=0: always use the threshold/compaction kernel (A/B runs)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRS_SCAN_DUMP"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+// workspace: [shared thresholds | partial scores | partial rows | stage-1 winners (scores, ids)]
+size_t ws_bytes(size_t part_elems, int nq, int k) {
+  return tau_bytes(nq) + 2 * align_up(part_elems * 4, 256) + align_up((size_t)nq * k * 4, 256) + align_up((size_t)nq * k * 8, 256);
+}
 
 int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   if (nq <= 0 || dim <= 0 || dim > 1024) return fail(CRS_EINVAL, "nq must be > 0 and 0 < dim <= 1024");
@@ -71,6 +83,19 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   p->nwg = p->n_tiles < streams ? p->n_tiles : streams;
   if (nqb > 1 && p->nwg >= 8) p->nwg &= ~7;
   p->kp = partial_width(k);
+  p->group_best = 0;
+  if (p->wide_nw) {                        // register chain of the K best group representatives per lane
+    p->kp = 2 * crs::scan_wide_slots(k);
+    p->group_best = 1;
+  } else if (slab_type == CRS_SLAB_F16 && k <= 16 && dump_enabled()) {
+    // short streams: every lane's per-tile best goes straight to the partial list (scan.hip, variant D)
+    // (merge.hip's single-pass path takes <= 8192 candidates per query)
+    const int tps = (p->n_tiles + p->nwg - 1) / p->nwg;
+    if ((size_t)tps * p->nwg <= 8192) {
+      p->kp = tps;
+      p->group_best = 1;
+    }
+  }
   p->part_elems = (size_t)p->nwg * nq * p->kp;
   return CRS_OK;
 }
@@ -126,14 +151,15 @@ int crs_scan_workspace_bytes(int nq, int dim, int k, int64_t n_rows, size_t* byt
   if (rc) return rc;
   // sized for the largest grid either slab type can use (resident workgroups), not for n_rows
   const size_t cap = (size_t)device_cus() * crs::scan_wg_per_cu();
-  *bytes = 2 * align_up(cap * nq * partial_width(k) * 4, 256) + tau_bytes(nq);
+  const size_t classic = ws_bytes(cap * nq * partial_width(k), nq, k);
+  const size_t planned = ws_bytes(p.part_elems, nq, k);
+  *bytes = classic > planned ? classic : planned;
   return CRS_OK;
 }
 
 static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const void* slab,
                     const float* scales, int64_t n_rows, int k, void* ws, hipStream_t st,
                     float** ps_out, int** pr_out) {
-  // workspace: [shared thresholds | partial scores | partial rows]
   unsigned* tau = reinterpret_cast<unsigned*>(ws);
   float* ps = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + tau_bytes(nq));
   int* pr = reinterpret_cast<int*>(reinterpret_cast<char*>(ps) + align_up(p.part_elems * 4, 256));
@@ -170,7 +196,8 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.nqb = p.nqb;
   const int e = p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
                 : (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
-                                             : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
+                : p.group_best ? crs::scan_launch_f16_dump(a, p.pdim, st)
+                               : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
   *ps_out = ps;
   *pr_out = pr;
   return e;
@@ -188,15 +215,27 @@ int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const v
     return fail(CRS_EINVAL, "null pointer");
   if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
   if (((uintptr_t)q16_dev | (uintptr_t)slab_dev) & 15) return fail(CRS_EINVAL, "q/slab must be 16-byte aligned");
-  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256) + tau_bytes(nq)) return fail(CRS_ENOSPC, "workspace too small");
+  if (workspace_bytes < ws_bytes(p.part_elems, nq, k)) return fail(CRS_ENOSPC, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* ps;
   int* pr;
   int e = run_scan(p, q16_dev, nq, slab_type, slab_dev, scales_dev, n_rows, k, workspace_dev, st, &ps, &pr);
   if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
   if (e) return hip_fail((hipError_t)e, "scan launch");
-  e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, id_base, out_scores_dev, out_ids_dev, st);
+  if (!p.group_best) {
+    e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, id_base, out_scores_dev, out_ids_dev, st);
+    if (e) return hip_fail((hipError_t)e, "merge launch");
+    return CRS_OK;
+  }
+  // group-best variants: k best representatives (local rows) -> their row groups re-scored and ranked
+  float* win_s = reinterpret_cast<float*>(reinterpret_cast<char*>(pr) + align_up(p.part_elems * 4, 256));
+  int64_t* win_i = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(win_s) + align_up((size_t)nq * k * 4, 256));
+  e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, 0, win_s, win_i, st);
   if (e) return hip_fail((hipError_t)e, "merge launch");
+  e = crs::refine_launch(reinterpret_cast<const _Float16*>(q16_dev), nq, p.pdim, reinterpret_cast<const _Float16*>(slab_dev),
+                         (int)n_rows, win_s, win_i, k, p.tile_rows, id_base, out_scores_dev, out_ids_dev, st);
+  if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
+  if (e) return hip_fail((hipError_t)e, "refine launch");
   return CRS_OK;
 }
 
@@ -227,7 +266,7 @@ int crs_time_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, co
   int rc = make_plan(nq, dim, k, n_rows, slab_type, &p);
   if (rc) return rc;
   if (iters <= 0 || !ms_total || !ms_scan) return fail(CRS_EINVAL, "bad iters / null outputs");
-  if (workspace_bytes < 2 * align_up(p.part_elems * 4, 256) + tau_bytes(nq)) return fail(CRS_ENOSPC, "workspace too small");
+  if (workspace_bytes < ws_bytes(p.part_elems, nq, k)) return fail(CRS_ENOSPC, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t e0, e1;
   hipError_t he;

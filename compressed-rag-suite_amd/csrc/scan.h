@@ -24,6 +24,10 @@ struct ScanArgs {
   int nqb;                // 64-query blocks; the grid is nqb * nwg workgroups (scan_common.h: grid mapping)
 };
 
+// scan_refine.hip: re-open the k winning tiles (16 or 32 rows each) per query, re-score, rank
+int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, int n_rows, const float* win_s,
+                  const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream);
+
 int scan_tile_rows(int pdim);
 int scan_i8_tile_rows();
 int scan_wg_per_cu();
@@ -31,9 +35,12 @@ bool scan_share_tau();  // CRS_SCAN_SHARE_TAU=0 disables cross-workgroup thresho
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
 int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
+// short streams (<= 16 tiles per workgroup), k <= 16: group-best dump, finished by merge + refine_launch
+int scan_launch_f16_dump(const ScanArgs& a, int pdim, hipStream_t stream);
 // scan_wide.hip: 65+ queries per launch, k <= 16, fp16 slabs
 int scan_wide_waves(int nq, int k, int pdim);
 int scan_wide_wg_per_cu(int nw, int pdim);
+int scan_wide_slots(int k);
 int scan_launch_wide(const ScanArgs& a, int pdim, int nw, hipStream_t stream);
 
 // merge.hip

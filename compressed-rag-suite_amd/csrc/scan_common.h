@@ -167,6 +167,19 @@ __device__ __forceinline__ float kth_of_quad(float (&s)[32], int k) {
   return __shfl(t, src);
 }
 
+// max over the lane pair (l, l ^ 32) / the lane quad (l, l ^ 16, l ^ 32, l ^ 48) with the gfx950 row
+// swaps (VALU, no LDS round trip: a ds_bpermute queues behind the tile reads of every wave of the CU).
+// v_permlane32_swap(D, S) exchanges lanes 32..63 of D with lanes 0..31 of S; fed the same register
+// twice it returns (low half broadcast, high half broadcast), whose max is the pair's max in all lanes.
+__device__ __forceinline__ float pair_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_max(float x) {   // v_permlane16_swap: odd 16-lane rows of D <-> even rows of S
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return pair_max(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+}
+
 // A pointer that IS wave-uniform (kernel argument + blockIdx arithmetic), made provably so for the
 // "s" (SGPR) operand of an inline-asm load: both halves go through v_readfirstlane.
 // HAZARD: an SGPR written by v_readfirstlane needs 5 wait states before a VMEM instruction may read

@@ -11,22 +11,30 @@
 //   * v_mfma_f32_32x32x16_f16, A = 32 slab rows of the tile (LDS), B = the wave's 32 queries, whose
 //     fragments for the full depth D stay in VGPRs for the whole kernel (D/4 registers);
 //     one ds_read_b128 now feeds 32 MFMA cycles instead of 16, and a tile is staged once per 256 queries;
-//   * result layout: lane l holds query (l & 31), rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of the tile,
-//     so a query's candidates live in a lane PAIR (l, l ^ 32): private LDS lists of 16 slots per lane,
-//     compaction = one in-register sorting network + ONE cross-lane merge (scan_common.h's quad version
-//     needs two);
+//   * result layout: lane l holds query (l & 31), rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of the tile:
+//     16 rows of the tile per lane, a query's scores live in a lane PAIR (l, l ^ 32);
+//   * selection is "tile best" (scan_refine.hip): per tile the lane pair reduces its 2 x 16 scores to the
+//     tile's best row (one xor-shuffle), and that single candidate is inserted into a register-resident
+//     sorted list of the K best so far (a branch-free compare-exchange chain, 5 VALU per slot).  The two
+//     lanes of a pair take turns -- lane half h inserts the tiles of parity h -- so the chain runs once
+//     per TWO tiles; nothing is filtered against a threshold, no LDS lists, no compaction.
+//     The first version of this kernel used scan.hip's per-lane LDS candidate lists + wave compaction:
+//     measured on C4 with 256 queries (tools/scan_wide_probe), of 1.13 M cycles per wave 0.38 M went to
+//     compactions (15 k cycles each, and with 8 waves behind one barrier every one of them stalls the
+//     workgroup), 0.26 M to the 16 data-dependent appends per tile and 0.24 M to the MFMAs.
+//     At the end every lane writes its K (score, row) pairs; merge.hip picks the k best representatives
+//     over all workgroups and scan_refine.hip re-opens their row groups;
 //   * tile staging, XOR swizzle (conflict-free for the 32-row fragment reads too: every 16-lane group of
 //     a ds_read_b128 covers 16 distinct rows mod 16), early asm loads and the one-barrier double buffer
 //     are those of scan.hip.
-// k <= 16 only (the launcher falls back to scan.hip otherwise).  Exactness argument unchanged: rows are
-// visited in ascending order inside a stream, the filter is a strict compare against the running k-th
-// best, ties on the threshold are resolved by row inside the compaction.
+// k <= 16 only (the launcher falls back to scan.hip otherwise).
 
 #include "scan_common.h"
 
 #include <stdlib.h>
 
 namespace crs {
+int scan_wide_slots(int k);
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,7 +53,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
 constexpr int WTR = 32;   // tile rows = one 32x32 MFMA row block
-constexpr int WL = 16;    // list slots per lane
 
 template <int D, int NW>
 struct WCfg {
@@ -54,120 +61,23 @@ struct WCfg {
   static constexpr int kTileBytes = WTR * D * 2;
   static constexpr int kLoads = kTileBytes / (kThreadsW * 16);
   static constexpr int kKsteps = D / 16;
-  static constexpr int kListBytes = NW * WL * 64 * 4;
-  static constexpr int kLds = 2 * kTileBytes + 2 * kListBytes;
+  static constexpr int kLds = 2 * kTileBytes;
   static_assert(D % 128 == 0, "row length must be a multiple of 128 elements");
   static_assert(kTileBytes % (kThreadsW * 16) == 0, "tile must split into whole 16-byte loads");
 };
-
-__device__ __forceinline__ int pair_sum(int x) { return x + __shfl_xor(x, 32); }
-__device__ __forceinline__ int pair_min(int x) { return min(x, __shfl_xor(x, 32)); }
-
-// k-th best (1-based) of the 32 candidates of this lane's query (16 here, 16 in lane ^ 32)
-__device__ __forceinline__ float kth_of_pair(float (&s)[16], int k) {
-  bitonic_sort_desc<16>(s);
-  float m[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) m[j] = fmaxf(s[j], __shfl_xor(s[15 - j], 32));
-  bitonic_clean_desc<16>(m);
-  return pick<16>(m, k - 1);
-}
-
-// As scan_common.h's compact(), for a query spread over the lane pair (l, l ^ 32).
-template <bool FINAL>
-__device__ __forceinline__ void compact2(float* __restrict__ sbuf, int* __restrict__ ibuf, int lane, int& cnt,
-                                         float& tau, int k, float* out_s, int* out_i, bool q_valid, int kp) {
-  constexpr int L = WL;
-  float v[L], s[L];
-  int id[L];
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    const bool in = j < cnt;
-    const float x = sbuf[j * 64 + lane];
-    v[j] = in ? x : kNegInf;
-    s[j] = v[j];
-    id[j] = ibuf[j * 64 + lane];
-  }
-  const int total = pair_sum(cnt);
-  const float tnew = kth_of_pair(s, k);   // -inf while the pair holds fewer than k candidates
-  int n_gt = 0, n_eq = 0;
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    n_gt += (j < cnt && v[j] > tnew) ? 1 : 0;
-    n_eq += (j < cnt && v[j] == tnew) ? 1 : 0;
-  }
-  n_gt = pair_sum(n_gt);
-  n_eq = pair_sum(n_eq);
-  const int need = (total >= k) ? (k - n_gt) : n_eq;
-  int idthr = 0x7fffffff;
-  if (__any(n_eq > need)) {   // ties on the threshold score: keep the `need` smallest rows among them
-    int thr = -1;
-    const int rounds = (n_eq > need) ? need : 0;
-    for (int it = 0; __any(it < rounds); ++it) {
-      int c = 0x7fffffff;
-#pragma unroll
-      for (int j = 0; j < L; ++j)
-        if (j < cnt && v[j] == tnew && id[j] > thr) c = min(c, id[j]);
-      c = pair_min(c);
-      if (it < rounds) thr = c;
-    }
-    if (n_eq > need) idthr = thr;
-  }
-  unsigned km = 0;
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    const bool keep = (j < cnt) && (v[j] > tnew || (v[j] == tnew && id[j] <= idthr));
-    km |= (keep ? 1u : 0u) << j;
-  }
-  const int c = __popc(km);
-  const int qb = lane & 31, g = lane >> 5;
-  const int c0 = __shfl(c, qb), c1 = __shfl(c, qb + 32);
-  const int prefix = g ? c0 : 0;
-  const int kept = c0 + c1;
-  if (FINAL) {
-    if (q_valid) {
-#pragma unroll
-      for (int j = 0; j < L; ++j) {
-        if ((km >> j) & 1u) {
-          const int p = prefix + __popc(km & ((1u << j) - 1u));
-          out_s[p] = v[j];
-          out_i[p] = id[j];
-        }
-      }
-      for (int p = kept + g; p < kp; p += 2) {
-        out_s[p] = kNegInf;
-        out_i[p] = -1;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      if ((km >> j) & 1u) {
-        const int p = prefix + __popc(km & ((1u << j) - 1u));
-        const int dl = qb + ((p & 1) << 5);
-        sbuf[(p >> 1) * 64 + dl] = v[j];
-        ibuf[(p >> 1) * 64 + dl] = id[j];
-      }
-    }
-    cnt = (kept - g + 1) >> 1;
-    if (total >= k) tau = fmaxf(tau, tnew);
-  }
-}
 
 // PF = tiles in flight per workgroup: 2 for the 8-wave configuration (one workgroup per CU) where the
 // registers allow it, else 1 (two workgroups per CU, or D = 512 whose query fragments fill the file).
 template <int D, int NW>
 constexpr int wide_pf() { return 1; }   // 2 measured no faster (the kernel was barrier-bound, below) and doubles the code
 
-template <int D, int NW>
+template <int D, int NW, int K>
 __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a) {
   using C = WCfg<D, NW>;
   constexpr int PF = wide_pf<D, NW>();
   constexpr int kT = C::kThreadsW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tile_buf = smem;
-  float* sbuf_all = reinterpret_cast<float*>(smem + 2 * C::kTileBytes);
-  int* ibuf_all = reinterpret_cast<int*>(smem + 2 * C::kTileBytes + C::kListBytes);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,15 +167,78 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
 #pragma unroll
   for (int j = 0; j < 8; ++j) a_off[j] = qn * (C::kCpr * 16) + (((2 * j + h) ^ qn) & 15) * 16;
 
-  float* sbuf = sbuf_all + wave * (WL * 64);
-  int* ibuf = ibuf_all + wave * (WL * 64);
-  float tau = q_valid ? kNegInf : __builtin_huge_valf();
-  int cnt = 0;
+  // this lane's K best tiles so far as (best score, first row), sorted: score desc, earlier tile first on ties
+  float ts[K];
+  int tr[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { ts[j] = kNegInf; tr[j] = -1; }
+
+  float px = kNegInf;   // pending candidate of this lane (see the loop)
+  int pr = -1;
+  // insert into the sorted list: one compare-exchange per slot, the loser moves on
+  auto insert = [&](float x, int xr) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const bool c = x > ts[j];
+      const float s_old = ts[j];
+      const int r_old = tr[j];
+      ts[j] = c ? x : s_old;
+      tr[j] = c ? xr : r_old;
+      x = c ? s_old : x;
+      xr = c ? r_old : xr;
+    }
+  };
 
   if constexpr (PF == 2) load_tile(st1, t + nwg);   // after the query loads: park_tile's counted wait then covers st0 + queries
   park_tile(st0, tile_buf);
   __syncthreads();
   WP_LAP(0);   // prologue
+
+  // Stagger (MI355X_MICROARCH.md, "two waves per SIMD", item 9).  Waves w and w + 4 share a SIMD, and with
+  // one barrier per tile they run in lockstep: both in their MFMA sweep (halving each other's rate), then
+  // both in the VALU selection with the matrix pipe idle -- measured 3.7 k cycles per tile against 1.5 k
+  // of MFMA work.  So waves 4..7 defer the selection of a tile by one iteration (its 16 accumulators stay
+  // in registers across the barrier): on every SIMD one wave multiplies while the other selects.
+  const bool late = (NW == 8 && D <= 384) && wave >= 4;   // wave-uniform (D = 512: no registers left for it)
+  f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto sweep = [&](const char* buf) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) {
+      const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 7] + (ks >> 3) * 256);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[ks], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+  // tile te (the ie-th of this stream): the tile's best score for this lane's query -> sorted list.
+  // The representative is (best score, first row of the tile): tiles are contiguous row ranges, so on
+  // equal scores the lower tile holds the lower rows and no arg-max is needed (scan_refine.hip).
+  auto select = [&](const f32x16& acc, int te, int ie) {
+    float x;
+    if (te < n_full) {
+      const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+      const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+      const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+      const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+      const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+      x = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)), __builtin_fmaxf(m4, acc[15]));
+    } else {   // ragged last tile: rows past the end must not win
+      x = kNegInf;
+      const int row_base = te * WTR + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_base + 8 * (r >> 2) + (r & 3);
+        x = (row < a.n_rows) ? __builtin_fmaxf(x, acc[r]) : x;
+      }
+    }
+    x = pair_max(x);                              // both halves: the tile's best
+    if ((ie & 1) == h) { px = x; pr = te * WTR; } // lane half h is responsible for the tiles of parity h
+    if (ie & 1) {
+      insert(px, pr);
+      px = kNegInf;
+      pr = -1;
+    }
+  };
 
   int cur = 0, it = 0;
   // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
@@ -273,39 +246,16 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
     if constexpr (PF == 2) load_tile(sy, t + 2 * nwg); else load_tile(sx, t + nwg);
     if (wave_active) {
       WP_LAP(1);   // tile-load issue
-      WP_LAP(2);
       const char* buf = tile_buf + cur * C::kTileBytes;
-      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < C::kKsteps; ++ks) {
-        const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 7] + (ks >> 3) * 256);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[ks], acc, 0, 0, 0);
-      }
-      WP_LAP(3);   // MFMA sweep
-      bool hit = false;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hit |= acc[r] > tau;
-      if (__any(hit)) {
-        const int row_base = t * WTR + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float sc = acc[4 * g + i];
-            const int row = row_base + 8 * g + i;
-            if (sc > tau && row < a.n_rows) {
-              sbuf[cnt * 64 + lane] = sc;
-              ibuf[cnt * 64 + lane] = row;
-              ++cnt;
-            }
-          }
-          if (__any(cnt > WL - 4)) {
-            WP_LAP(4);
-            compact2<false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0);
-            WP_COUNT(9);
-            WP_LAP(5);   // on-demand compaction
-          }
-        }
+      if (!late) {
+        f32x16 acc = sweep(buf);
+        WP_LAP(3);   // MFMA sweep
+        select(acc, t, it);
+      } else {       // waves 4..7: last tile's selection first, then this tile's MFMAs
+        if (it > 0) select(acc_prev, t - nwg, it - 1);
+        WP_LAP(2);
+        acc_prev = sweep(buf);
+        WP_LAP(3);
       }
     }
     WP_LAP(4);   // filter + append
@@ -328,40 +278,25 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail prefetches (clamped re-reads) must not outlive the kernel's registers
 
-  if (wave_active) {
-    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + stream) * a.kp;   // [nq, nwg, kp]
-    float* out_s = a.part_scores + o;
-    int* out_i = a.part_rows + o;
-    const int total = pair_sum(cnt);
-    if (__any(total > a.kp)) {
-      compact2<true>(sbuf, ibuf, lane, cnt, tau, a.k, out_s, out_i, q_valid, a.kp);
-    } else {   // every query holds <= kp candidates: a superset of its top-k, dump as is
-      const int c0 = __shfl(cnt, qn);
-      const int prefix = h ? c0 : 0;
-      if (q_valid) {
+  if (wave_active && late && it > 0) select(acc_prev, t - nwg, it - 1);   // the deferred last tile
+  if (wave_active && (it & 1)) insert(px, pr);   // odd tile count: the last (even) tile is still pending
+  if (wave_active && q_valid) {   // [nq, nwg, kp = 2 K]: lane half h owns slots h K .. h K + K - 1
+    const size_t o = ((size_t)qi * nwg + stream) * a.kp + (size_t)h * K;
 #pragma unroll
-        for (int j = 0; j < WL; ++j) {
-          if (j < cnt) {
-            out_s[prefix + j] = sbuf[j * 64 + lane];
-            out_i[prefix + j] = ibuf[j * 64 + lane];
-          }
-        }
-        for (int p = total + h; p < a.kp; p += 2) {
-          out_s[p] = kNegInf;
-          out_i[p] = -1;
-        }
-      }
+    for (int j = 0; j < K; ++j) {
+      a.part_scores[o + j] = ts[j];
+      a.part_rows[o + j] = tr[j];
     }
   }
   WP_LAP(10);   // final flush
   WP_STORE(NW);
 }
 
-template <int D, int NW>
+template <int D, int NW, int K>
 int launch_wide(const ScanArgs& a, hipStream_t stream) {
   using C = WCfg<D, NW>;
   static bool done = false;
-  auto kernel = &scan_wide_kernel<D, NW>;
+  auto kernel = &scan_wide_kernel<D, NW, K>;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
@@ -372,12 +307,17 @@ int launch_wide(const ScanArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+template <int D, int NW>
+int launch_wide_k(const ScanArgs& a, hipStream_t stream) {
+  const int kk = scan_wide_slots(a.k);
+  if (kk == 4) return launch_wide<D, NW, 4>(a, stream);
+  if (kk == 10) return launch_wide<D, NW, 10>(a, stream);
+  return launch_wide<D, NW, 16>(a, stream);
+}
+
 template <int D>
 int launch_wide_d(const ScanArgs& a, int nw, hipStream_t stream) {
-  if constexpr (D <= 384) {
-    if (nw == 4) return launch_wide<D, 4>(a, stream);
-  }
-  return nw == 8 ? launch_wide<D, 8>(a, stream) : -1;
+  return nw == 8 ? launch_wide_k<D, 8>(a, stream) : launch_wide_k<D, 4>(a, stream);
 }
 
 }  // namespace
@@ -391,14 +331,12 @@ int scan_wide_waves(int nq, int k, int pdim) {
     on = (e && e[0] == '0') ? 0 : 1;
   }
   if (!on || nq <= 64 || k > 16 || pdim > 512) return 0;
-  return (nq > 128 || pdim > 384) ? 8 : 4;   // <512, 4 waves> would spill
+  return nq > 128 ? 8 : 4;
 }
-// resident workgroups per CU: 8 waves = 112..128 KB of LDS -> 1; 4 waves (<= 96 KB) -> 1 or 2
-int scan_wide_wg_per_cu(int nw, int pdim) {
-  if (nw == 8) return 1;
-  const int lds = 2 * WTR * pdim * 2 + 2 * nw * WL * 64 * 4;
-  return lds <= 80 * 1024 ? 2 : 1;
-}
+// list slots per lane the kernel is instantiated for (>= k); the partial lists are 2 * this wide
+int scan_wide_slots(int k) { return k <= 4 ? 4 : k <= 10 ? 10 : 16; }
+// resident workgroups per CU: the query fragments cost D/4 registers per lane -> two waves per SIMD
+int scan_wide_wg_per_cu(int nw, int pdim) { return nw == 8 ? 1 : 2; }
 
 int scan_launch_wide(const ScanArgs& a, int pdim, int nw, hipStream_t stream) {
   switch (pdim) {

@@ -84,3 +84,34 @@ def test_wide_agrees_with_narrow_kernel(cuda, monkeypatch):
         ns, ni = _run(cuda, q[lo:lo + 64], c, 10)
         assert np.array_equal(ni, gi[lo:lo + 64])
         assert np.array_equal(ns, gs[lo:lo + 64])
+
+
+# ---- group-best specifics (scan_refine.hip): several top-k rows inside ONE row group / one tile
+@pytest.mark.parametrize("nq", [8, 200])
+def test_topk_rows_share_a_group(cuda, nq):
+    q, c = _case(5000, 384, nq, seed=5)
+    c = c.copy()
+    full = scan_ref.full_scores_f64(q, c)
+    best = int(full[0].argmax())
+    # rows 2048..2051 and 2064..2067 sit in one lane's group of tile 64 (32-row tiles); 2056.. in a sibling
+    for pos in (2048, 2049, 2050, 2051, 2064, 2065, 2056, 2057):
+        c[pos] = c[best]
+    c[2052] = (c[best].astype(np.float32) * 0.999).astype(np.float16)
+    gs, gi = _run(cuda, q, c, 10)
+    full = scan_ref.full_scores_f64(q, c)
+    check_topk(gs, gi, full, 10)
+    rs, ri = scan_ref.cosine_topk_ref(q, c, 10)
+    assert np.array_equal(gi[0], ri[0])
+
+
+@pytest.mark.parametrize("d,nq", [(768, 16), (1024, 40), (384, 64), (256, 130)])
+def test_every_row_of_one_tile_wins(cuda, d, nq):
+    """The whole top-16 is one contiguous run of rows (a single tile, all of its groups)."""
+    q, c = _case(3000, d, nq, seed=2)
+    c = c.copy()
+    v = q[0].astype(np.float32)
+    for j in range(16):
+        c[1600 + j] = (v * (1.0 - 0.001 * j)).astype(np.float16)
+    for k in (16, 5):
+        gs, gi = _run(cuda, q, c, k)
+        check_topk(gs, gi, scan_ref.full_scores_f64(q, c), k)

@@ -30,14 +30,14 @@ int main(int argc, char** argv) {
   for (auto& x : hq) x = (_Float16)(rnd() * sc);
   _Float16 *slab, *q; float* ps; int* pr; unsigned long long* st;
   hipMalloc(&slab, h.size() * 2); hipMalloc(&q, hq.size() * 2);
-  hipMalloc(&ps, (size_t)nwg * nq * 16 * 4); hipMalloc(&pr, (size_t)nwg * nq * 16 * 4);
+  hipMalloc(&ps, (size_t)nwg * nq * 32 * 4); hipMalloc(&pr, (size_t)nwg * nq * 32 * 4);
   const size_t nst = (size_t)nwg * nqb * nw * 12;
   hipMalloc(&st, nst * 8);
   hipMemcpy(slab, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(q, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
   crs::ScanArgs a{};
   a.q = q; a.slab = slab; a.part_scores = ps; a.part_rows = pr; a.stamps = st;
-  a.n_rows = rows; a.n_tiles = n_tiles; a.nq = nq; a.k = k; a.kp = k; a.nwg = nwg; a.nqb = nqb; a.sched = 2;
+  a.n_rows = rows; a.n_tiles = n_tiles; a.nq = nq; a.k = k; a.kp = 2 * crs::scan_wide_slots(k); a.nwg = nwg; a.nqb = nqb; a.sched = 2;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < 4; ++rep) {
