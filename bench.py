@@ -283,7 +283,7 @@ def main():
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "scan_f16_kernel" if slab_type == nat.SLAB_F16 else "scan_i8_kernel",
+                "kernel": nat.scan_plan_describe(nq_all, dim, k, rows, slab_type),
                 "kernel_ms": round(ms_scan, 5), "scan_plus_merge_ms": round(ms_total, 5),
                 "algorithmic_bytes": int(alg_bytes)}
 

@@ -42,6 +42,8 @@ struct Plan {
   int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
   int nqb;                                 // query blocks (64 queries each; 32 * wide_nw for the wide kernel)
   int wide_nw;                             // > 0: scan_wide.hip with this many waves per workgroup
+  int tb_nw;                               // > 0: scan_tb.hip with this many waves per workgroup
+  int tb_slots;                            //   its chain length (0: dump mode)
   int group_best;                          // 1: the scan leaves tile representatives (scan_refine.hip finishes)
   size_t part_elems;  // nwg * nq * kp
 };
@@ -51,9 +53,9 @@ struct Plan {
 int partial_width(int k) { return (crs::scan_share_tau() && k <= 16) ? 16 : k; }
 size_t tau_bytes(int nq) { return align_up16((size_t)nq * 4); }
 
-bool dump_enabled() {   // CRS_SCAN_DUMP=0: always use the threshold/compaction kernel (A/B runs)
+bool tb_enabled() {   // CRS_SCAN_TB=0: always use the threshold/compaction kernel for <= 64 queries (A/B runs, tests)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CRS_SCAN_DUMP"); v = (e && e[0] == '0') ? 0 : 1; }
+  if (v < 0) { const char* e = getenv("CRS_SCAN_TB"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
 }
 
@@ -69,12 +71,17 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   const int cus = device_cus();
   if (cus <= 0) return fail(CRS_EHIP, "no HIP device available%s");
   p->pdim = crs_row_elems(dim, slab_type);
+  // kernel family: classic threshold/compaction scan (k > 16, int8), or one of the tile-best kernels
   p->wide_nw = slab_type == CRS_SLAB_F16 ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
+  p->tb_nw = 0;
+  if (!p->wide_nw && slab_type == CRS_SLAB_F16 && k <= 16 && tb_enabled())
+    p->tb_nw = (nq > 64 && crs::scan_tb_has_8_waves(p->pdim)) ? 8 : 4;
   p->tile_rows = p->wide_nw ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
-  const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim) : crs::scan_wg_per_cu());
+  const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim)
+                         : p->tb_nw ? crs::scan_tb_wg_per_cu(p->pdim, p->tb_nw) : crs::scan_wg_per_cu());
   // all query blocks of a tile stream must be co-resident: streams = resident slots / query blocks
-  const int qpb = p->wide_nw ? 32 * p->wide_nw : 64;
+  const int qpb = p->wide_nw ? 32 * p->wide_nw : p->tb_nw ? 16 * p->tb_nw : 64;
   const int nqb = (nq + qpb - 1) / qpb;
   p->nqb = nqb;
   int streams = cap / nqb;
@@ -84,16 +91,20 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   if (nqb > 1 && p->nwg >= 8) p->nwg &= ~7;
   p->kp = partial_width(k);
   p->group_best = 0;
-  if (p->wide_nw) {                        // register chain of the K best group representatives per lane
+  p->tb_slots = 0;
+  if (p->wide_nw) {                        // register chain of the K best tile representatives per lane
     p->kp = 2 * crs::scan_wide_slots(k);
     p->group_best = 1;
-  } else if (slab_type == CRS_SLAB_F16 && k <= 16 && dump_enabled()) {
-    // short streams: every lane's per-tile best goes straight to the partial list (scan.hip, variant D)
-    // (merge.hip's single-pass path takes <= 8192 candidates per query)
+  } else if (p->tb_nw) {
+    // short streams: every tile's representative goes straight to the partial list ("dump"; merge.hip's
+    // single-pass path takes <= 8192 candidates per query); longer ones keep the K best in registers
     const int tps = (p->n_tiles + p->nwg - 1) / p->nwg;
-    if ((size_t)tps * p->nwg <= 8192) {
+    p->group_best = 1;
+    if ((size_t)tps * p->nwg <= 8192 && tps <= 2 * crs::scan_wide_slots(k)) {
       p->kp = tps;
-      p->group_best = 1;
+    } else {
+      p->tb_slots = crs::scan_wide_slots(k);
+      p->kp = p->tb_slots;
     }
   }
   p->part_elems = (size_t)p->nwg * nq * p->kp;
@@ -196,7 +207,7 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.nqb = p.nqb;
   const int e = p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
                 : (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
-                : p.group_best ? crs::scan_launch_f16_dump(a, p.pdim, st)
+                : p.tb_nw ? crs::scan_launch_tb(a, p.pdim, p.tb_nw, p.tb_slots, st)
                                : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
   *ps_out = ps;
   *pr_out = pr;
@@ -255,6 +266,21 @@ int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_d
   const int e = crs::rescore_launch(q32_dev, nq, dim, shadow_dev, n_rows, id_base, k, scores_dev,
                                     ids_dev, (hipStream_t)stream);
   return e ? hip_fail((hipError_t)e, "rescore launch") : CRS_OK;
+}
+
+int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type, char* buf, size_t cap) {
+  if (!buf || cap == 0) return fail(CRS_EINVAL, "null buffer");
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
+  Plan p;
+  const int rc = make_plan(nq, dim, k, n_rows, slab_type, &p);
+  if (rc) return rc;
+  char name[96];
+  if (p.wide_nw) snprintf(name, sizeof name, "scan_wide_kernel<%d,%d,%d>", p.pdim, p.wide_nw, crs::scan_wide_slots(k));
+  else if (p.tb_nw) snprintf(name, sizeof name, "scan_tb_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, p.tb_nw, p.tb_slots);
+  else if (slab_type == CRS_SLAB_I8) snprintf(name, sizeof name, "scan_i8_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
+  else snprintf(name, sizeof name, "scan_f16_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
+  snprintf(buf, cap, "%s streams=%d qblocks=%d kp=%d + merge%s", name, p.nwg, p.nqb, p.kp, p.group_best ? " + refine" : "");
+  return CRS_OK;
 }
 
 int crs_time_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,

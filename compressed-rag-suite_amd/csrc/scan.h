@@ -35,8 +35,11 @@ bool scan_share_tau();  // CRS_SCAN_SHARE_TAU=0 disables cross-workgroup thresho
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
 int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
-// short streams (<= 16 tiles per workgroup), k <= 16: group-best dump, finished by merge + refine_launch
-int scan_launch_f16_dump(const ScanArgs& a, int pdim, hipStream_t stream);
+// scan_tb.hip: tile-best 16x16x32 scan, k <= 16; nw = 4 (64 queries / workgroup) or 8 (128);
+// slots = 0: dump mode (kp = tiles per stream), else chain mode (kp = slots); finished by merge + refine_launch
+int scan_tb_wg_per_cu(int pdim, int nw);
+bool scan_tb_has_8_waves(int pdim);
+int scan_launch_tb(const ScanArgs& a, int pdim, int nw, int slots, hipStream_t stream);
 // scan_wide.hip: 65+ queries per launch, k <= 16, fp16 slabs
 int scan_wide_waves(int nq, int k, int pdim);
 int scan_wide_wg_per_cu(int nw, int pdim);

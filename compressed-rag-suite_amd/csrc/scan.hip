@@ -461,151 +461,6 @@ int launch_kernel(K kernel, int lds, const ScanArgs& a, int nwg, hipStream_t str
   return (int)hipGetLastError();
 }
 
-// ---- variant D ("dump"): SHORT streams (<= 16 tiles per workgroup, e.g. C2's 100 k rows: 6).
-// With so few tiles the threshold machinery above is all overhead: on C2 the bootstrap, two in-loop
-// compactions and the final one were a third of every wave's 57 k cycles, and the kernel sat at 0.34 of
-// the HBM roofline.  Here nothing is filtered, listed or compacted: per tile each lane keeps only the
-// BEST of the 8 (TR = 32) or 4 (TR = 16) scores that land in its accumulators; two row swaps reduce the
-// query's four lanes to the tile's best score, which goes with the tile's first row straight to the
-// workgroup's partial list, slot tile_no.  merge.hip then picks the k best
-// representatives and scan_refine.hip re-opens their tiles (exactness argument there).  No LDS lists,
-// no data-dependent branch in the loop.
-template <int D, int TR>
-__global__ __launch_bounds__(kThreads, 2) void scan_f16_dump_kernel(const ScanArgs a) {
-  using C = Cfg<D, TR, 16>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* tile_buf = smem;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = CRS_NSTREAMS;
-  const int stream = CRS_STREAM;
-  const bool wave_active = (CRS_QBLOCK * 64 + wave * 16) < a.nq;
-
-  int lds_dst[C::kLoads];
-#pragma unroll
-  for (int j = 0; j < C::kLoads; ++j) {
-    const int P = j * kThreads + tid;
-    const int r = P / C::kCpr, c = P % C::kCpr;
-    lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
-  }
-  const char* slab = reinterpret_cast<const char*>(a.slab);
-  const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
-  const int n_full = a.n_rows / TR;
-  u32x4 st[C::kLoads];
-  auto load_tile = [&](int tile_) {
-    const int tile = __builtin_amdgcn_readfirstlane(tile_);
-    if (tile < n_full) {
-      const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
-#pragma unroll
-      for (int j = 0; j < C::kLoads; ++j) {
-        const unsigned off = (unsigned)(j * kThreads + tid) * 16u;
-        u32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-        st[j] = x;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < C::kLoads; ++j) {
-        size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
-        off = off > last_chunk ? last_chunk : off;
-        const char* p = slab + off;
-        u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-        st[j] = x;
-      }
-    }
-  };
-  auto park_tile = [&](char* dst) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      u32x4 x = st[j];
-      asm volatile("" : "+v"(x));
-      st[j] = x;
-    }
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
-  };
-
-  int t = stream;
-  load_tile(t);
-  const int lr = lane & 15, kq = lane >> 4;
-  const int qi = CRS_QBLOCK * 64 + wave * 16 + lr;
-  const bool q_valid = qi < a.nq;
-  f16x8 qf[C::kKsteps];
-  {
-    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
-#pragma unroll
-    for (int ks = 0; ks < C::kKsteps; ++ks) {
-      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 32) : z;
-    }
-#pragma unroll
-    for (int ks = 0; ks < C::kKsteps; ++ks) {
-      f16x8 x = qf[ks];
-      asm volatile("" : "+v"(x));
-      qf[ks] = x;
-    }
-  }
-  int a_off[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
-  // the query's slots in the partial list [nq, nwg, kp]: slot it for the it-th tile of the stream
-  const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + stream) * a.kp;
-  float* out_s = a.part_scores + o;
-  int* out_i = a.part_rows + o;
-  park_tile(tile_buf);
-  __syncthreads();
-
-  int cur = 0, it = 0;
-  for (; t < a.n_tiles; t += nwg) {
-    load_tile(t + nwg);
-    if (wave_active) {
-      const char* buf = tile_buf + cur * C::kTileBytes;
-      float best = kNegInf;
-#pragma unroll
-      for (int rt = 0; rt < C::kRt; ++rt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < C::kKsteps; ++ks) {
-          const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
-        }
-        if (t < n_full) {
-          best = fmaxf(best, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
-        } else {   // ragged last tile: rows past the end must not win
-          const int row0 = t * TR + rt * 16 + kq * 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) best = (row0 + i < a.n_rows) ? fmaxf(best, acc[i]) : best;
-        }
-      }
-      best = quad_max(best);   // the query's four lanes: all rows of the tile
-      if (q_valid && kq == 0) {
-        out_s[it] = best;
-        out_i[it] = t * TR;    // representative = (tile best, first row of the tile); see scan_refine.hip
-      }
-    }
-    park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
-    __syncthreads();
-    cur ^= 1;
-    ++it;
-  }
-  if (wave_active && q_valid) {   // slots of tiles this (shorter) stream does not have
-    for (int p = it + kq; p < a.kp; p += 4) {
-      out_s[p] = kNegInf;
-      out_i[p] = -1;
-    }
-  }
-}
-
-template <int D, int TR>
-int launch_dump(const ScanArgs& a, hipStream_t stream) {
-  using C = Cfg<D, TR, 16>;
-  static bool done = false;
-  return launch_kernel(&scan_f16_dump_kernel<D, TR>, 2 * C::kTileBytes, a, a.nwg, stream, &done);
-}
-
 template <int D, int TR, int L>
 int launch_l(const ScanArgs& a, int nwg, hipStream_t stream) {
   using C = Cfg<D, TR, L>;
@@ -659,20 +514,6 @@ bool scan_share_tau() {
 }
 
 int scan_tile_rows(int pdim) { return pdim <= 512 ? 32 : 16; }
-
-int scan_launch_f16_dump(const ScanArgs& a, int pdim, hipStream_t stream) {
-  switch (pdim) {
-    case 128: return launch_dump<128, 32>(a, stream);
-    case 256: return launch_dump<256, 32>(a, stream);
-    case 384: return launch_dump<384, 32>(a, stream);
-    case 512: return launch_dump<512, 32>(a, stream);
-    case 640: return launch_dump<640, 16>(a, stream);
-    case 768: return launch_dump<768, 16>(a, stream);
-    case 896: return launch_dump<896, 16>(a, stream);
-    case 1024: return launch_dump<1024, 16>(a, stream);
-    default: return -1;
-  }
-}
 
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream) {
   switch (pdim) {

@@ -1,0 +1,344 @@
+// scan_tb.hip -- "tile best" form of the 16x16x32 scan (fp16 slabs, k <= 16): the default for 64-query
+// batches, and for larger batches of rows wider than 512 elements (scan_wide.hip takes the others).
+//
+// scan.hip filters every score against a running per-query threshold, appends survivors to per-lane
+// LDS lists and compacts them with in-register sorting networks.  Measured on C2 (100 k rows, 6 tiles
+// per workgroup) that machinery -- bootstrap, two in-loop compactions, the final one -- was a third of
+// every wave's 57 k cycles and the kernel sat at 0.34 of the HBM roofline; its 80 KB of LDS per workgroup
+// also caps residency at two workgroups (two tiles in flight) per CU.
+// Here a wave keeps, per query and tile, only the tile's best score (max tree over the lane's
+// accumulators + two row swaps across the query's four lanes) filed under the tile's first row; merge.hip
+// picks the k best tiles per query and scan_refine.hip re-opens them (exactness argument there):
+//   * K = 0, "dump": streams of at most a few tiles write every representative straight to the
+//     workgroup's partial list (slot = tile number in the stream);
+//   * K > 0, "chain": the representative goes into a register-resident sorted list of the K best so far
+//     (branch-free compare-exchange chain, 5 VALU per slot).  A query's four lanes take turns -- lane
+//     group kq inserts the tiles with (tile number & 3) == kq -- so the chain runs once per FOUR tiles.
+// No LDS lists, no data-dependent branch, 2 tiles of LDS per workgroup: three workgroups (tiles in
+// flight) per CU where the registers allow.  NW = 4 waves serve 64 queries; NW = 8 serve 128 from one
+// staged copy of the tile (rows wider than 512 elements, where scan_wide.hip's 32-query fragments no
+// longer fit the register file).
+
+#include "scan_common.h"
+
+#include <stdlib.h>
+
+namespace crs {
+namespace {
+
+template <int D, int TR, int NW>
+struct TbCfg {
+  static constexpr int kT = NW * 64;
+  static constexpr int kCpr = D / 8;
+  static constexpr int kTileBytes = TR * D * 2;
+  static constexpr int kLoads = kTileBytes / (kT * 16);
+  static constexpr int kKsteps = D / 32;
+  static constexpr int kRt = TR / 16;
+  static constexpr int kLds = 2 * kTileBytes;
+  // resident workgroups per CU the kernel is built for (LDS and a 512 / waves-per-SIMD register budget)
+  static constexpr int kWgpc = NW == 8 ? (D <= 384 ? 2 : 1) : (D <= 384 ? 3 : 2);
+  // tiles in flight per workgroup: a second register staging set where the register budget has room
+  static constexpr int kPf = (NW == 4 && D <= 384) ? 2 : 1;
+  static_assert(D % 128 == 0 && TR % 16 == 0, "row length: multiple of 128 elements; tile rows: multiple of 16");
+  static_assert(kTileBytes % (kT * 16) == 0, "tile must split into whole 16-byte loads");
+};
+
+template <int D, int TR, int NW, int K>
+__global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void scan_tb_kernel(const ScanArgs a) {
+  using C = TbCfg<D, TR, NW>;
+  constexpr int kT = C::kT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile_buf = smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = CRS_NSTREAMS;
+  const int stream = CRS_STREAM;
+  const int qbase = CRS_QBLOCK * (NW * 16) + wave * 16;
+  const bool wave_active = qbase < a.nq;
+
+  int lds_dst[C::kLoads];
+#pragma unroll
+  for (int j = 0; j < C::kLoads; ++j) {
+    const int P = j * kT + tid;
+    const int r = P / C::kCpr, c = P % C::kCpr;
+    lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+  }
+  const char* slab = reinterpret_cast<const char*>(a.slab);
+  const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
+  const int n_full = a.n_rows / TR;
+  constexpr int PF = (C::kPf == 2 && K <= 10) ? 2 : 1;   // K = 16: the chain leaves no room for the second set
+  u32x4 st0[C::kLoads], st1[PF == 2 ? C::kLoads : 1];
+  auto load_tile = [&](auto& st, int tile_) {
+    const int tile = __builtin_amdgcn_readfirstlane(tile_);
+    if (tile < n_full) {
+      const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
+#pragma unroll
+      for (int j = 0; j < C::kLoads; ++j) {
+        const unsigned off = (unsigned)(j * kT + tid) * 16u;
+        u32x4 x;
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
+        st[j] = x;
+      }
+    } else {   // ragged last tile, or past the end: clamp every lane to the slab's last 16 bytes
+#pragma unroll
+      for (int j = 0; j < C::kLoads; ++j) {
+        size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kT + tid) * 16;
+        off = off > last_chunk ? last_chunk : off;
+        const char* p = slab + off;
+        u32x4 x;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
+        st[j] = x;
+      }
+    }
+  };
+  // wait until all but the youngest tile's loads have landed (vmcnt counts in issue order), then move
+  // this set into LDS
+  auto park_tile = [&](auto& st, char* dst) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF == 2 ? C::kLoads : 0) : "memory");
+#pragma unroll
+    for (int j = 0; j < C::kLoads; ++j) {
+      u32x4 x = st[j];
+      asm volatile("" : "+v"(x));
+      st[j] = x;
+    }
+#pragma unroll
+    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
+  };
+
+  int t = stream;
+  load_tile(st0, t);   // before the query fragments are fetched: the two latencies overlap
+  const int lr = lane & 15, kq = lane >> 4;
+  const int qi = qbase + lr;
+  const bool q_valid = qi < a.nq;
+  f16x8 qf[C::kKsteps];
+  {
+    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) {
+      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 32) : z;
+    }
+#pragma unroll
+    for (int ks = 0; ks < C::kKsteps; ++ks) {
+      f16x8 x = qf[ks];
+      asm volatile("" : "+v"(x));
+      qf[ks] = x;
+    }
+  }
+  int a_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a_off[m] = lr * (C::kCpr * 16) + (((m * 4 + kq) ^ lr) & 15) * 16;
+  // the query's slots in the partial list [nq, nwg, kp]
+  const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + stream) * a.kp;
+  float* out_s = a.part_scores + o;
+  int* out_i = a.part_rows + o;
+
+  // chain mode: this lane's K best tiles so far as (best score, first row), sorted; earlier tile first on ties
+  constexpr int KK = K > 0 ? K : 1;
+  float ts[KK];
+  int tr[KK];
+#pragma unroll
+  for (int j = 0; j < KK; ++j) { ts[j] = kNegInf; tr[j] = -1; }
+  float px = kNegInf;   // pending candidate of this lane
+  int pr = -1;
+  auto insert = [&](float x, int xr) {
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      const bool c = x > ts[j];
+      const float s_old = ts[j];
+      const int r_old = tr[j];
+      ts[j] = c ? x : s_old;
+      tr[j] = c ? xr : r_old;
+      x = c ? s_old : x;
+      xr = c ? r_old : xr;
+    }
+  };
+
+  if constexpr (PF == 2) load_tile(st1, t + nwg);   // after the query loads: the counted wait below covers st0 + queries
+  park_tile(st0, tile_buf);
+  __syncthreads();
+
+  int cur = 0, it = 0;
+  // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
+  auto body = [&](auto& sx, auto& sy) {
+    if constexpr (PF == 2) load_tile(sy, t + 2 * nwg); else load_tile(sx, t + nwg);
+    if (wave_active) {
+      const char* buf = tile_buf + cur * C::kTileBytes;
+      float best = kNegInf;
+#pragma unroll
+      for (int rt = 0; rt < C::kRt; ++rt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::kKsteps; ++ks) {
+          const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
+        }
+        if (t < n_full) {
+          best = fmaxf(best, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+        } else {   // ragged last tile: rows past the end must not win
+          const int row0 = t * TR + rt * 16 + kq * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) best = (row0 + i < a.n_rows) ? fmaxf(best, acc[i]) : best;
+        }
+      }
+      best = quad_max(best);   // the query's four lanes: all rows of the tile
+      if constexpr (K == 0) {
+        if (q_valid && kq == 0) {
+          out_s[it] = best;
+          out_i[it] = t * TR;
+        }
+      } else {
+        if ((it & 3) == kq) { px = best; pr = t * TR; }   // lane group kq is responsible for these tiles
+        if ((it & 3) == 3) {
+          insert(px, pr);
+          px = kNegInf;
+          pr = -1;
+        }
+      }
+    }
+    park_tile(sx, tile_buf + (cur ^ 1) * C::kTileBytes);
+    __syncthreads();
+    cur ^= 1;
+    ++it;
+    t += nwg;
+  };
+  if constexpr (PF == 2) {
+    while (t < a.n_tiles) {
+      body(st1, st0);
+      if (t >= a.n_tiles) break;
+      body(st0, st1);
+    }
+  } else {
+    while (t < a.n_tiles) body(st0, st0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail prefetches (clamped re-reads) must not outlive the registers
+  if (wave_active) {
+    if constexpr (K == 0) {
+      if (q_valid) {   // slots of tiles this (shorter) stream does not have
+        for (int p = it + kq; p < a.kp; p += 4) {
+          out_s[p] = kNegInf;
+          out_i[p] = -1;
+        }
+      }
+    } else {
+      insert(px, pr);   // tiles of an unfinished round of four (a no-op for lanes with nothing pending)
+      // Fold the four lanes' lists into the query's K best: each lane inserts its partner's K entries
+      // (lane ^ 16, then lane ^ 32); afterwards all four hold the same list and one of them writes it.
+      // Entries of different lanes arrive out of tile order, so here ties are decided by the full
+      // (score desc, first row asc) comparison.
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        float os[KK];
+        int orow[KK];
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+          if (round == 0) {
+            const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
+            const auto rr = __builtin_amdgcn_permlane16_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
+            os[j] = __uint_as_float((kq & 1) ? rs[0] : rs[1]);     // [0]: even 16-lane rows, [1]: odd rows
+            orow[j] = (int)((kq & 1) ? rr[0] : rr[1]);
+          } else {
+            const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
+            const auto rr = __builtin_amdgcn_permlane32_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
+            os[j] = __uint_as_float((kq & 2) ? rs[0] : rs[1]);     // [0]: lanes 0..31, [1]: lanes 32..63
+            orow[j] = (int)((kq & 2) ? rr[0] : rr[1]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < KK; ++e) {
+          float x = os[e];
+          int xr = orow[e];
+#pragma unroll
+          for (int j = 0; j < KK; ++j) {
+            const bool c = xr >= 0 && (x > ts[j] || (x == ts[j] && (xr < tr[j] || tr[j] < 0)));
+            const float s_old = ts[j];
+            const int r_old = tr[j];
+            ts[j] = c ? x : s_old;
+            tr[j] = c ? xr : r_old;
+            x = c ? s_old : x;
+            xr = c ? r_old : xr;
+          }
+        }
+      }
+      if (q_valid && kq == 0) {    // kp = K
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          out_s[j] = ts[j];
+          out_i[j] = tr[j];
+        }
+      }
+    }
+  }
+}
+
+template <int D, int TR, int NW, int K>
+int launch_tb(const ScanArgs& a, hipStream_t stream) {
+  using C = TbCfg<D, TR, NW>;
+  static bool done = false;
+  auto kernel = &scan_tb_kernel<D, TR, NW, K>;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(a.nqb * a.nwg), dim3(NW * 64), C::kLds, stream, a);
+  return (int)hipGetLastError();
+}
+
+template <int D, int TR, int NW>
+int launch_tb_k(const ScanArgs& a, int slots, hipStream_t stream) {
+  switch (slots) {
+    case 0: return launch_tb<D, TR, NW, 0>(a, stream);
+    case 4: return launch_tb<D, TR, NW, 4>(a, stream);
+    case 10: return launch_tb<D, TR, NW, 10>(a, stream);
+    case 16: return launch_tb<D, TR, NW, 16>(a, stream);
+    default: return -1;
+  }
+}
+
+template <int D, int TR>
+int launch_tb_d(const ScanArgs& a, int nw, int slots, hipStream_t stream) {
+  if constexpr ((TR * D * 2) % (8 * 64 * 16) == 0) {
+    if (nw == 8) return launch_tb_k<D, TR, 8>(a, slots, stream);
+  }
+  return nw == 4 ? launch_tb_k<D, TR, 4>(a, slots, stream) : -1;
+}
+
+}  // namespace
+
+// 8 waves need a tile that splits into whole 16-byte loads over 512 threads (not 640- / 896-element rows)
+bool scan_tb_has_8_waves(int pdim) { return pdim != 640 && pdim != 896; }
+
+int scan_tb_wg_per_cu(int pdim, int nw) {
+  if (nw == 8 && !scan_tb_has_8_waves(pdim)) nw = 4;
+  switch (pdim) {
+    case 128: return nw == 8 ? TbCfg<128, 32, 8>::kWgpc : TbCfg<128, 32, 4>::kWgpc;
+    case 256: return nw == 8 ? TbCfg<256, 32, 8>::kWgpc : TbCfg<256, 32, 4>::kWgpc;
+    case 384: return nw == 8 ? TbCfg<384, 32, 8>::kWgpc : TbCfg<384, 32, 4>::kWgpc;
+    case 512: return nw == 8 ? TbCfg<512, 32, 8>::kWgpc : TbCfg<512, 32, 4>::kWgpc;
+    case 640: return TbCfg<640, 16, 4>::kWgpc;
+    case 768: return nw == 8 ? TbCfg<768, 16, 8>::kWgpc : TbCfg<768, 16, 4>::kWgpc;
+    case 896: return TbCfg<896, 16, 4>::kWgpc;
+    case 1024: return nw == 8 ? TbCfg<1024, 16, 8>::kWgpc : TbCfg<1024, 16, 4>::kWgpc;
+    default: return 2;
+  }
+}
+
+// slots = 0: dump mode (kp = tiles per stream); else chain mode with that many slots (kp = slots)
+int scan_launch_tb(const ScanArgs& a, int pdim, int nw, int slots, hipStream_t stream) {
+  switch (pdim) {
+    case 128: return launch_tb_d<128, 32>(a, nw, slots, stream);
+    case 256: return launch_tb_d<256, 32>(a, nw, slots, stream);
+    case 384: return launch_tb_d<384, 32>(a, nw, slots, stream);
+    case 512: return launch_tb_d<512, 32>(a, nw, slots, stream);
+    case 640: return launch_tb_d<640, 16>(a, nw, slots, stream);
+    case 768: return launch_tb_d<768, 16>(a, nw, slots, stream);
+    case 896: return launch_tb_d<896, 16>(a, nw, slots, stream);
+    case 1024: return launch_tb_d<1024, 16>(a, nw, slots, stream);
+    default: return -1;
+  }
+}
+
+}  // namespace crs

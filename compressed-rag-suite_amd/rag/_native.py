@@ -33,6 +33,7 @@ _SIGNATURES = {
                                c_void_p]),
     "crs_rescore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                 c_void_p, c_void_p]),
+    "crs_scan_plan_describe": (c_int, [c_int, c_int, c_int, c_int64, c_int, ctypes.c_char_p, c_size_t]),
     "crs_time_cosine_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
                                      c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                                      POINTER(c_float), POINTER(c_float)]),
@@ -160,6 +161,13 @@ def rescore_f32(q32, shadow, n_rows: int, id_base: int, scores, ids) -> None:
     k = scores.shape[1]
     check(load().crs_rescore_f32(_ptr(q32), nq, dim, _ptr(shadow), n_rows, id_base, k, _ptr(scores),
                                  _ptr(ids), _stream_ptr()))
+
+
+def scan_plan_describe(nq: int, dim: int, k: int, n_rows: int, slab_type: int = SLAB_F16) -> str:
+    """Kernel family + launch geometry crs_cosine_topk would use (for bench lines and profiles)."""
+    buf = ctypes.create_string_buffer(256)
+    check(load().crs_scan_plan_describe(nq, dim, k, n_rows, slab_type, buf, 256))
+    return buf.value.decode()
 
 
 def time_cosine_topk(q16, slab, n_rows: int, dim: int, k: int, iters: int, *, slab_type: int = SLAB_F16,

@@ -83,6 +83,11 @@ int crs_merge_topk(const float* scores_dev, const int64_t* ids_dev, int nlists, 
 int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
                     int64_t id_base, int k, float* scores_dev, int64_t* ids_dev, void* stream);
 
+/* Which scan kernel (and launch geometry) crs_cosine_topk would use for these sizes on the current
+ * device, as text, e.g. "scan_tb_kernel<384,32,4,0> streams=768 qblocks=1 kp=5 + merge + refine".
+ * For bench.py / profiles only; writes at most `cap` bytes including the terminator. */
+int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type, char* buf, size_t cap);
+
 /* Timing hook for bench.py: runs `iters` back-to-back crs_cosine_topk launches bracketed by
  * hipEvents on `stream` and returns the mean milliseconds of ONE launch pair (scan + merge)
  * in *ms_total and of the scan kernel alone in *ms_scan. */
