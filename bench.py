@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--scan-only", action="store_true", help="diagnostic: skip the encoder (NOT the metric)")
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=32,
                     help="independent query batches in flight on separate HIP streams (1 GPU runs only)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the per-rank query batch size")
@@ -156,8 +156,10 @@ def main():
     # The step is three device segments with the two exchanges between them; every segment reads and
     # writes fixed buffers of its Ctx, so each can be captured once into a hipGraph and replayed.
     def seg_encode(c):      # token ids -> fp16 queries of this rank
-        q = q32 if args.scan_only else enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws)
-        nat.queries_to_f16(q, slab_type, out=c.q16)
+        if args.scan_only:
+            nat.queries_to_f16(q32, slab_type, out=c.q16)
+        else:   # pooled embeddings leave the encoder as fp32 and as the scan's fp16 query block
+            enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=slab_type)
 
     def seg_scan(c):        # all queries of the step x this rank's shard -> per-shard top-k
         nat.cosine_topk(c.q_all if world > 1 else c.q16, slab, rows, dim, k, slab_type=slab_type, scales=scales,
@@ -230,7 +232,7 @@ def main():
     with torch.cuda.stream(streams[0]):
         fin_s, fin_i = step(ctxs[0])
     streams[0].synchronize()
-    q_chk = (nat.queries_to_f16(q32, slab_type) if world == 1 else ctxs[0].q_all).float()[:, :dim]
+    q_chk = (ctxs[0].q16 if world == 1 else ctxs[0].q_all).float()[:, :dim]
     ref_s = torch.full((nq_all, k), float("-inf"), device=dev)
     ref_i = torch.full((nq_all, k), -1, dtype=torch.int64, device=dev)
     for lo in range(0, rows, 250_000):

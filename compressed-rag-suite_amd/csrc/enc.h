@@ -29,6 +29,6 @@ int layernorm_launch(const float* y, int nsplit, const float* bias, const float*
                      const float* b, float eps, int tokens, int hidden, float* x32, _Float16* x16,
                      hipStream_t stream);
 int pool_launch(const float* x32, const int* lens, int batch, int seq, int hidden, int pooling, int normalize,
-                float* out, hipStream_t stream);
+                float* out, _Float16* out16, int pdim16, hipStream_t stream);
 
 }  // namespace crs

@@ -99,10 +99,10 @@ int crs_gemm_f16(const void* a_dev, const void* w_dev, const float* bias_dev, co
   return CRS_OK;
 }
 
-int crs_encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights* w, const int32_t* ids_dev,
-                        const int32_t* lens_dev, int batch, int seq, void* workspace_dev,
-                        size_t workspace_bytes, float* out_dev, int normalize, float* hidden_out_dev,
-                        void* stream) {
+static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights* w, const int32_t* ids_dev,
+                           const int32_t* lens_dev, int batch, int seq, void* workspace_dev,
+                           size_t workspace_bytes, float* out_dev, int normalize, float* hidden_out_dev,
+                           _Float16* q16_out_dev, int q16_row_elems, void* stream) {
   const int rc = check_desc(d);
   if (rc) return rc;
   if (!w || !w->layers || !ids_dev || !lens_dev || !workspace_dev || !out_dev) return crs::set_error(CRS_EINVAL, "null pointer");
@@ -149,8 +149,27 @@ int crs_encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights* w,
     const hipError_t e = hipMemcpyAsync(hidden_out_dev, x32, (size_t)T * H * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return crs::set_error(CRS_EHIP, hipGetErrorString(e));
   }
-  CRS_TRY(crs::pool_launch(x32, lens_dev, batch, seq, H, d->pooling, normalize, out_dev, st), "pool");
+  CRS_TRY(crs::pool_launch(x32, lens_dev, batch, seq, H, d->pooling, normalize, out_dev, q16_out_dev, q16_row_elems, st), "pool");
   return CRS_OK;
+}
+
+int crs_encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights* w, const int32_t* ids_dev,
+                        const int32_t* lens_dev, int batch, int seq, void* workspace_dev,
+                        size_t workspace_bytes, float* out_dev, int normalize, float* hidden_out_dev,
+                        void* stream) {
+  return encoder_forward(d, w, ids_dev, lens_dev, batch, seq, workspace_dev, workspace_bytes, out_dev, normalize,
+                         hidden_out_dev, nullptr, 0, stream);
+}
+
+int crs_encoder_forward_queries(const crs_encoder_desc* d, const crs_encoder_weights* w, const int32_t* ids_dev,
+                                const int32_t* lens_dev, int batch, int seq, void* workspace_dev,
+                                size_t workspace_bytes, float* out_dev, void* q16_out_dev, int slab_type,
+                                void* stream) {
+  if (!q16_out_dev) return crs::set_error(CRS_EINVAL, "null pointer");
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return crs::set_error(CRS_EINVAL, "bad slab_type");
+  if (!d) return crs::set_error(CRS_EINVAL, "null descriptor");
+  return encoder_forward(d, w, ids_dev, lens_dev, batch, seq, workspace_dev, workspace_bytes, out_dev, 1, nullptr,
+                         reinterpret_cast<_Float16*>(q16_out_dev), crs_row_elems(d->hidden, slab_type), stream);
 }
 
 }  // extern "C"

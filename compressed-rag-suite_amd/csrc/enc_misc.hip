@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // unrolled so several rows are in flight per thread.
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x32, const int* __restrict__ lens,
                                                   int batch, int seq, int hidden, int pooling, int normalize,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ out, _Float16* __restrict__ out16, int pdim16) {
   __shared__ float red[4];
   const int bi = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x32
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i;
     if (c < hidden) out[(size_t)bi * hidden + c] = v[i] * scale;
+    // optional fp16 copy in the scan's query layout (row zero-padded to pdim16): saves the separate
+    // normalise + cast launch between the encoder and the scan
+    if (out16 && c < pdim16) out16[(size_t)bi * pdim16 + c] = (c < hidden) ? (_Float16)(v[i] * scale) : (_Float16)0.f;
   }
 }
 
@@ -188,9 +191,9 @@ int layernorm_launch(const float* y, int nsplit, const float* bias, const float*
 }
 
 int pool_launch(const float* x32, const int* lens, int batch, int seq, int hidden, int pooling, int normalize,
-                float* out, hipStream_t stream) {
+                float* out, _Float16* out16, int pdim16, hipStream_t stream) {
   hipLaunchKernelGGL(pool_kernel, dim3(batch), dim3(256), 0, stream, x32, lens, batch, seq, hidden,
-                     pooling, normalize, out);
+                     pooling, normalize, out, out16, pdim16);
   return (int)hipGetLastError();
 }
 

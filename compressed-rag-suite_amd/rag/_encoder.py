@@ -37,6 +37,8 @@ nat.register_signatures({
     "crs_encoder_workspace_bytes": (c_int, [POINTER(EncoderDesc), c_int, c_int, POINTER(c_size_t)]),
     "crs_encoder_forward": (c_int, [POINTER(EncoderDesc), POINTER(EncoderWeights), c_void_p, c_void_p, c_int,
                                     c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),
+    "crs_encoder_forward_queries": (c_int, [POINTER(EncoderDesc), POINTER(EncoderWeights), c_void_p, c_void_p, c_int,
+                                            c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
     "crs_gemm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_void_p]),
 })
@@ -121,9 +123,12 @@ class HipEncoder:
         nat.check(nat.load().crs_encoder_workspace_bytes(byref(self.desc), batch, seq, byref(out)))
         return int(out.value)
 
-    def forward(self, ids, lens, normalize: bool = True, return_hidden: bool = False, out=None, workspace=None):
+    def forward(self, ids, lens, normalize: bool = True, return_hidden: bool = False, out=None, workspace=None,
+                q16_out=None, slab_type: int = nat.SLAB_F16):
         """ids: int32 [B, S] (numpy or cuda tensor, right padded), lens: int32 [B].
-        Returns cuda fp32 [B, H] (and [B, S, H] hidden states when return_hidden)."""
+        Returns cuda fp32 [B, H] (and [B, S, H] hidden states when return_hidden).  With `q16_out`
+        (cuda fp16 [B, padded_dim]) the pooled, normalised embeddings are also written there in the scan's
+        query layout (crs_encoder_forward_queries)."""
         import torch
         if not isinstance(ids, torch.Tensor):
             ids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32))
@@ -142,6 +147,15 @@ class HipEncoder:
             raise ValueError(f"encoder workspace too small: {ws.numel()} < {need}")
         if out is None:
             out = torch.empty((b, self.shape.hidden), dtype=torch.float32, device=self.device)
+        if q16_out is not None:
+            if return_hidden or not normalize:
+                raise ValueError("q16_out needs normalize=True and return_hidden=False")
+            if tuple(q16_out.shape) != (b, nat.padded_dim(self.shape.hidden, slab_type)) or q16_out.dtype != torch.float16:
+                raise ValueError("q16_out must be fp16 [batch, padded_dim]")
+            nat.check(nat.load().crs_encoder_forward_queries(byref(self.desc), byref(self.weights), nat._ptr(ids),
+                                                             nat._ptr(lens), b, s, nat._ptr(ws), ws.numel(), nat._ptr(out),
+                                                             nat._ptr(q16_out), slab_type, nat._stream_ptr()))
+            return out
         hidden = torch.empty((b, s, self.shape.hidden), dtype=torch.float32, device=self.device) if return_hidden else None
         nat.check(nat.load().crs_encoder_forward(byref(self.desc), byref(self.weights), nat._ptr(ids), nat._ptr(lens),
                                                  b, s, nat._ptr(ws), ws.numel(), nat._ptr(out),

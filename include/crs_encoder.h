@@ -71,6 +71,15 @@ int crs_encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights* w,
                         size_t workspace_bytes, float* out_dev, int normalize, float* hidden_out_dev,
                         void* stream);
 
+/* Query-side variant of crs_encoder_forward (always L2-normalised): besides the fp32 embeddings it writes
+ * them as the fp16 query block crs_cosine_topk takes -- [batch, crs_row_elems(H, slab_type)], zero padded --
+ * from the pooling kernel itself, which saves the separate crs_queries_to_f16 launch on the retrieve path
+ * (rag/retrieval.py:113-121: embed the query, then search). */
+int crs_encoder_forward_queries(const crs_encoder_desc* d, const crs_encoder_weights* w, const int32_t* ids_dev,
+                                const int32_t* lens_dev, int batch, int seq, void* workspace_dev,
+                                size_t workspace_bytes, float* out_dev, void* q16_out_dev, int slab_type,
+                                void* stream);
+
 /* Building block exported for parity tests and for users with their own layer stack:
  *   C[M, N] = epilogue(A[M, K] (fp16) x W[N, K]^T (fp16) + bias[N])
  *   mode 0: fp16 out;  mode 1: erf-GELU, fp16 out;  mode 2: + residual fp32 [M, N], fp32 out. */

@@ -106,3 +106,27 @@ def test_padding_is_ignored(cuda):
     wide[:, :20] = ids
     b = enc.forward(wide, lens).cpu().numpy()
     assert np.abs(a - b).max() < 2e-5
+
+
+@pytest.mark.parametrize("cfg,slab", [(er.MINILM_L6, 0), (er.BGE_BASE, 1), (er.TINY, 0)])
+def test_forward_queries_writes_the_scan_query_block(cuda, cfg, slab):
+    """crs_encoder_forward_queries: the fp16 block must be the normalised embedding cast to fp16 (what
+    crs_queries_to_f16 produces from the fp32 output, up to one fp16 ulp from re-normalising a unit
+    vector) with exact zero padding, and the fp32 output must be unchanged."""
+    import torch
+    from rag import _native as nat
+    enc, w = _encoder(cfg, 31, cuda)
+    ids, mask = er.synth_tokens(cfg, 5, 16, seed=32)
+    lens = mask.sum(1).astype(np.int32)
+    ref32 = enc.forward(ids, lens).clone()
+    pd = nat.padded_dim(cfg.hidden, slab)
+    q16 = torch.full((5, pd), 7.0, dtype=torch.float16, device=cuda)
+    out32 = enc.forward(ids, lens, q16_out=q16, slab_type=slab)
+    torch.cuda.synchronize()
+    assert torch.equal(out32, ref32)
+    assert (q16[:, cfg.hidden:] == 0).all()
+    via = nat.queries_to_f16(ref32, slab)
+    a, b = q16[:, :cfg.hidden].float(), via[:, :cfg.hidden].float()
+    assert (a - b).abs().max().item() <= 2.0 ** -11 * max(1e-3, b.abs().max().item()) * 2
+    same = (q16[:, :cfg.hidden] == ref32.half()).float().mean().item()
+    assert same > 0.995, f"only {same:.4f} of the fp16 components equal the cast fp32 output"
