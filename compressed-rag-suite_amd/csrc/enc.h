@@ -15,6 +15,12 @@ int gemm_panel_chunk(int k);
 int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
                       int mode, hipStream_t stream);
 
+// enc_rowln.hip: x = LayerNorm(A W^T + bias + residual) in one kernel (query-batch regime; hidden 384 / 768)
+bool gemm_rowln_supported(int hidden, int k);
+int gemm_rowln_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, const float* g,
+                      const float* b, float eps, int m, int hidden, int k, float* x32, _Float16* x16,
+                      hipStream_t stream);
+
 // enc_attn.hip: ctx[T, H] = softmax(QK^T / sqrt(hd) + padding mask) V per (batch, head);
 // qkv is [T, 3H] fp16 (Q | K | V column blocks), lens[b] real tokens per row (right padding).
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,

@@ -14,6 +14,7 @@
 #include "../../include/crs_hip.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "enc.h"
 
@@ -24,6 +25,18 @@ int set_error(int code, const char* msg);  // capi.hip
 namespace {
 
 size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+// The fused projection + LayerNorm kernel (enc_rowln.hip) is OFF by default: measured on MI355X it is
+// correct but slower than the pair it replaces (MiniLM, 64 x 16 tokens: forward 0.442 ms against 0.292 ms).
+// A workgroup that owns whole rows must stream all of W itself, and a CU ingests only ~50 B/clk through
+// LDS-DMA (~150 cycles of issue per 1 KiB wave-instruction): 1.7 us per 57 KB K-chunk, i.e. 10 us for
+// K = 384 and 41 us for K = 1536, where the split-N / split-K panel GEMM spreads the same bytes over 48-96
+// CUs.  CRS_ENC_ROWLN=1 enables it for experiments.
+bool rowln_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRS_ENC_ROWLN"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
 
 struct Layout {
   size_t x32, y32, x16, ctx, qkv, ffn, total;
@@ -122,13 +135,18 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   CRS_TRY(crs::embed_ln_launch(ids_dev, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, d->ln_eps, T,
                                seq, H, d->vocab_size, x32, x16, st), "embed_ln");
   const bool panel_h = use_panel(T, H), panel_f = use_panel(T, F);
+  // query-batch regime: projection + bias + residual + LayerNorm as one kernel (enc_rowln.hip)
+  const bool fuse_ln = T <= kPanelMaxTokens && rowln_enabled();
+  const bool rowln_h = fuse_ln && crs::gemm_rowln_supported(H, H), rowln_f = fuse_ln && crs::gemm_rowln_supported(H, F);
   const bool single_h = panel_h && crs::gemm_panel_chunk(H) == H;   // K = H fits one chunk: fused fp16 epilogues
   for (int li = 0; li < d->layers; ++li) {
     const crs_encoder_layer& L = w->layers[li];
     if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, qkv, T, 3 * H, H, 0, st), "qkv gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, nullptr, qkv, T, 3 * H, H, 0, st), "qkv gemm");
     CRS_TRY(crs::attention_launch(qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "attention");
-    if (panel_h) {
+    if (rowln_h) {
+      CRS_TRY(crs::gemm_rowln_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out gemm + layernorm 1");
+    } else if (panel_h) {
       CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, H / crs::gemm_panel_chunk(H), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
     } else {
@@ -137,7 +155,9 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
     }
     if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_up, L.b_up, ffn, T, F, H, 1, st), "ffn up gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");
-    if (panel_f) {
+    if (rowln_f) {
+      CRS_TRY(crs::gemm_rowln_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down gemm + layernorm 2");
+    } else if (panel_f) {
       CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, st), "ffn down gemm");
       CRS_TRY(crs::layernorm_launch(y32, F / crs::gemm_panel_chunk(F), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
     } else {
