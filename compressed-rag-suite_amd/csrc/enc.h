@@ -9,6 +9,12 @@ namespace crs {
 int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual,
                     void* out, int m, int n, int k, int mode, hipStream_t stream);
 
+// enc_gemm_stream.hip: row-streaming variant for short contractions (K in {128, 256, 384, 512}) and many rows:
+// W fragments resident in VGPRs, A streamed once per 128-column block
+bool gemm_stream_supported(int k);
+int gemm_stream_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out,
+                       int m, int n, int k, int mode, hipStream_t stream);
+
 // Panel variant for small M (one K chunk per workgroup, all loads issued at once; split-K over
 // blockIdx.z with fp32 partials [k/kc][M][N] in mode 3, summed by layernorm_launch).
 int gemm_panel_chunk(int k);

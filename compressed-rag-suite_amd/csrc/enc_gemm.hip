@@ -18,6 +18,8 @@
 
 #include "enc.h"
 
+#include <stdlib.h>
+
 namespace crs {
 namespace {
 
@@ -293,8 +295,18 @@ int launch_panel(const _Float16* a, const _Float16* w, const float* bias, void* 
 
 }  // namespace
 
+static bool stream_enabled() {   // CRS_GEMM_STREAM=0: always the tiled kernel (A/B runs)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRS_GEMM_STREAM"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual,
                     void* out, int m, int n, int k, int mode, hipStream_t stream) {
+  // short contraction, many rows, wide output (the index-build side's QKV and FFN-up projections): the tiled kernel
+  // below spends as long in its prologue and epilogue as in its K / 64 steps; stream rows past resident W
+  if (m >= 512 && n >= 512 && mode != 2 && gemm_stream_supported(k) && stream_enabled())
+    return gemm_stream_launch(a, w, bias, residual, out, m, n, k, mode, stream);
   dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
   switch (mode) {
     case 0: hipLaunchKernelGGL((gemm_f16_kernel<0>), grid, dim3(kThreads), 0, stream, a, w, bias, residual, out, m, n, k); break;

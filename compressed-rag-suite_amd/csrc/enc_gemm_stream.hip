@@ -13,7 +13,11 @@
 //     swizzle, next tile's loads issued (inline asm) before the current tile's MFMAs;
 //   * per tile and wave: K/16 v_mfma_f32_32x32x16_f16 on one accumulator, then the epilogue
 //     (bias / erf-GELU / +residual) straight from the accumulator registers.
-// Grid: blockIdx.x = 128-column block (fastest), blockIdx.y = row stream, so the column blocks that
+// Grid: 1-D, ncb * nstreams workgroups; workgroup b serves column block (b >> 3) % ncb of row stream
+// ((b >> 3) / ncb) * 8 + (b & 7): the column blocks of one stream sit on ids b, b + 8, ... = ONE XCD, so
+// an A tile is fetched from HBM / the Infinity Cache once and re-read from that XCD's L2 (with column block
+// fastest the nine blocks of the QKV projection landed on eight XCDs and the 450 MB of re-reads per launch
+// ran at the Infinity Cache's ~5 TB/s).  (Was: blockIdx.x = column block, blockIdx.y = row stream, so the column blocks that
 // share an A tile run together and A is fetched from HBM once.  One barrier per tile.
 
 #include "enc.h"
@@ -28,6 +32,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int TR = 32;     // A rows per tile
 constexpr int WN = 128;    // output columns per workgroup (4 waves x 32)
+constexpr int kEpiStride = 40;   // halves per row of the wave-private epilogue tile (32 + 8: 80-byte rows, 16-byte aligned)
 
 __device__ __forceinline__ float gelu_erf_s(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
                                                                  const _Float16* __restrict__ W,
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ residual,
-                                                                 void* __restrict__ out, int M, int N) {
+                                                                 void* __restrict__ out, int M, int N, int ncb, int nstreams) {
   constexpr int kCpr = K / 8;                     // 16-byte chunks per row
   constexpr int kTileBytes = TR * K * 2;
   constexpr int kLoads = kTileBytes / (kThreads * 16);
@@ -63,8 +68,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
   const int fr = lane & 31, fh = lane >> 5;
   const int n_tiles = (M + TR - 1) / TR;
   const int n_full = M / TR;
-  const int nstreams = gridDim.y;
-  const int col = blockIdx.x * WN + wave * 32 + fr;      // this lane's output column
+  const int bid = (int)blockIdx.x;
+  const int cblk = (nstreams & 7) ? bid % ncb : (bid >> 3) % ncb;
+  const int strm = (nstreams & 7) ? bid / ncb : ((bid >> 3) / ncb) * 8 + (bid & 7);
+  const int col = cblk * WN + wave * 32 + fr;      // this lane's output column
   const bool col_ok = col < N;
 
   // staging geometry (chunk P = j*256 + tid of the tile -> swizzled LDS offset), as in scan.hip
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
     for (int j = 0; j < kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };
 
-  int t = blockIdx.y;
+  int t = strm;
   load_tile(t);
 
   // W fragments of this wave's 32 columns: B[k][n] with n = lane & 31, k = 16 ks + 8 (lane >> 5) + j
@@ -152,22 +159,47 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
       const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 7] + (ks >> 3) * 256);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf[ks], acc, 0, 0, 0);
     }
-    // epilogue from registers: lane holds column `col`, rows (r & 3) + 8 (r >> 2) + 4 fh of the tile
-    if (col_ok) {
+    // epilogue: lane holds column `col`, rows (r & 3) + 8 (r >> 2) + 4 fh of the tile
+    if (MODE == 2) {   // fp32 + residual: straight from the registers (64-byte segments per row)
+      if (col_ok) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = t * TR + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (row < M) {
-          float v = acc[r] + bcol;
-          const size_t at = (size_t)row * N + col;
-          if (MODE == 1) v = gelu_erf_s(v);
-          if (MODE == 2) {
-            reinterpret_cast<float*>(out)[at] = v + residual[at];
-          } else {
-            reinterpret_cast<_Float16*>(out)[at] = (_Float16)v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = t * TR + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (row < M) {
+            const size_t at = (size_t)row * N + col;
+            reinterpret_cast<float*>(out)[at] = (acc[r] + bcol) + residual[at];
           }
         }
       }
+    } else {
+      // fp16 outputs go through a wave-private LDS tile so that a lane stores 16 bytes of one row: two
+      // global stores per 32 x 32 tile instead of sixteen 2-byte-per-lane ones (a vector-memory
+      // instruction costs the wave ~100 cycles of issue whatever its width, and sixteen of them per tile
+      // took longer than the tile's 24 MFMAs)
+      _Float16* my = reinterpret_cast<_Float16*>(smem + 2 * kTileBytes) + wave * (32 * kEpiStride);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r] + bcol;
+        if (MODE == 1) v = gelu_erf_s(v);
+        my[((r & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int c0 = cblk * WN + wave * 32;            // first column of this wave's block
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int lrow = half * 16 + (lane >> 2), lc = (lane & 3) * 8;
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&my[lrow * kEpiStride + lc]);
+        const int row = t * TR + lrow;
+        if (row < M) {
+          _Float16* dst = reinterpret_cast<_Float16*>(out) + (size_t)row * N + c0 + lc;
+          if (c0 + lc + 7 < N && (N & 7) == 0) {
+            *reinterpret_cast<f16x8*>(dst) = h;
+          } else {
+            for (int e = 0; e < 8 && c0 + lc + e < N; ++e) dst[e] = h[e];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     park_tile(smem + (cur ^ 1) * kTileBytes);
     __syncthreads();
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
 template <int K, int MODE>
 int launch_k(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n,
              int cus, hipStream_t stream) {
-  constexpr int lds = 2 * TR * K * 2;
+  constexpr int lds = 2 * TR * K * 2 + 4 * 32 * kEpiStride * 2;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<K, MODE>),
@@ -191,8 +223,10 @@ int launch_k(const _Float16* a, const _Float16* w, const float* bias, const floa
   int streams = (cus * 2) / colblocks;      // 2 workgroups / CU resident; column blocks of a stream run together
   if (streams < 1) streams = 1;
   if (streams > n_tiles) streams = n_tiles;
-  dim3 grid(colblocks, streams);
-  hipLaunchKernelGGL((gemm_stream_kernel<K, MODE>), grid, dim3(kThreads), lds, stream, a, w, bias, residual, out, m, n);
+  if (streams >= 8) streams &= ~7;          // whole rounds over the 8 XCDs
+  dim3 grid(colblocks * streams);
+  hipLaunchKernelGGL((gemm_stream_kernel<K, MODE>), grid, dim3(kThreads), lds, stream, a, w, bias, residual, out, m, n,
+                     colblocks, streams);
   return (int)hipGetLastError();
 }
 
