@@ -204,13 +204,22 @@ def main():
                 step(c)
         st.synchronize()
         if use_graph:
-            gl = []
-            for seg in segs:
-                g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_, stream=st):
-                    seg(c)
-                gl.append(g_)
-            c.graphs = gl
+            # thread_local: with N > 1 the process group's watchdog thread polls events while we capture;
+            # only this thread's calls belong to the capture.  If a capture fails anyway, run eagerly.
+            try:
+                gl = []
+                for seg in segs:
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
+                        seg(c)
+                    gl.append(g_)
+                c.graphs = gl
+            except Exception as exc:   # noqa: BLE001 -- report and keep going without graphs
+                print(f"[bench] hipGraph capture failed on rank {rank} ({exc!r}); launching eagerly", file=sys.stderr, flush=True)
+                use_graph = False
+                for cc in ctxs:
+                    cc.graphs = None
+                torch.cuda.synchronize()   # (no break: every rank must still run the same warm-up collectives)
     sync()
 
     def run(n):
