@@ -10,7 +10,7 @@ struct ScanArgs {
   const void* slab;       // [n_rows, D] fp16 (or int8)
   const float* scales;    // int8 slabs: one fp32 per row, else nullptr
   float* part_scores;     // [nq, nwg, kp]
-  int* part_rows;         // [nwg, nq, k] local row index, -1 = empty
+  int* part_rows;         // [nq, nwg, kp] local row index (tile-best kernels: first row of the tile), -1 = empty
   unsigned* tau_shared;   // [nq] order-preserving uint of the best published k-th score (0 = none); may be null
   unsigned long long* stamps;  // diagnostics only (tools/scan_probe); nullptr in the product path
   int n_rows;
@@ -19,9 +19,9 @@ struct ScanArgs {
   int k;
   int sched;              // synchronous-compaction schedule: 0 none, 1 {3,4,6,8,12,...}, 2 {4,8,16,...}
   int boot;               // 1: bootstrap the threshold from the first 64 rows in registers (scan.hip)
-  int kp;                 // slots per (query, workgroup) partial list: >= k (16 when k <= 16)
+  int kp;                 // slots per (query, workgroup) partial list (capi.hip make_plan: k, tiles per stream, or chain slots)
   int nwg;                // tile streams (workgroups per query block)
-  int nqb;                // 64-query blocks; the grid is nqb * nwg workgroups (scan_common.h: grid mapping)
+  int nqb;                // query blocks (64, 128 or 256 queries each); the grid is nqb * nwg workgroups (scan_common.h: grid mapping)
 };
 
 // scan_refine.hip: re-open the k winning tiles (16 or 32 rows each) per query, re-score, rank
@@ -30,8 +30,8 @@ int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, i
 
 int scan_tile_rows(int pdim);
 int scan_i8_tile_rows();
-int scan_wg_per_cu();
-bool scan_share_tau();  // CRS_SCAN_SHARE_TAU=0 disables cross-workgroup threshold sharing  // resident workgroups per CU the active scan variant is launched with
+int scan_wg_per_cu();    // resident workgroups per CU the active scan.hip variant is launched with
+bool scan_share_tau();  // CRS_SCAN_SHARE_TAU=1 enables cross-workgroup threshold sharing (scan.hip; measured slower, off)
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
 int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);

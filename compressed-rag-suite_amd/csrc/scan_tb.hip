@@ -102,8 +102,12 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
       asm volatile("" : "+v"(x));
       st[j] = x;
     }
+#if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT == 2
+    if (st[0][0] == 0x7fc01234u) *reinterpret_cast<u32x4*>(dst + lds_dst[0]) = st[0];   // keep the loads alive
+#else
 #pragma unroll
     for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
+#endif
   };
 
   int t = stream;
@@ -163,7 +167,11 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
   auto body = [&](auto& sx, auto& sy) {
     if constexpr (PF == 2) load_tile(sy, t + 2 * nwg); else load_tile(sx, t + nwg);
+#ifdef CRS_TB_EXPERIMENT   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either) */
+    if (false) {
+#else
     if (wave_active) {
+#endif
       const char* buf = tile_buf + cur * C::kTileBytes;
       float best = kNegInf;
 #pragma unroll
