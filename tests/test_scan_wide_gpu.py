@@ -115,3 +115,42 @@ def test_every_row_of_one_tile_wins(cuda, d, nq):
     for k in (16, 5):
         gs, gi = _run(cuda, q, c, k)
         check_topk(gs, gi, scan_ref.full_scores_f64(q, c), k)
+
+
+# ---- rows wider than 512 elements: scan_tb.hip with 8 waves (128 queries / workgroup), or 4 waves x several
+# query blocks where a 16-row tile does not split over 512 threads (640, 896); chain mode needs long streams
+@pytest.mark.parametrize("n,d,nq,k", [
+    (3000, 768, 130, 10),     # 8 waves, two query blocks (XCD-aware grid)
+    (2000, 1024, 100, 16),    # 8 waves, k at the selector's edge
+    (2500, 640, 70, 6),       # 4 waves x 2 query blocks
+    (1800, 896, 200, 3),      # 4 waves x 4 query blocks
+    (150_000, 768, 64, 10),   # dump -> chain switch-over region for 16-row tiles (12 tiles / stream)
+    (400_000, 384, 64, 10),   # chain mode, 3 workgroups / CU, prefetch depth 2
+    (400_000, 384, 64, 16),   # chain mode, 16 slots (single staging set)
+    (300_000, 128, 32, 4),    # chain mode, 4 slots, one idle wave pair
+])
+def test_tile_best_variants(cuda, n, d, nq, k):
+    q, c = _case(n, d, nq, seed=(n + d) % 5)
+    gs, gi = _run(cuda, q, c, k)
+    rs, ri = scan_ref.cosine_topk_ref(q, c, k, accumulate=np.float64)
+    assert np.abs(gs - rs).max() < 2e-5
+    mism = gi != ri
+    assert (np.abs(gs - rs)[mism] < 4e-6).all()          # any id mismatch is a near-tie in score
+    assert np.mean([scan_ref.recall_at_k(gi[r], ri[r]) for r in range(nq)]) > 0.995
+
+
+def test_chain_mode_ties_across_lanes_and_streams(cuda):
+    """Long stream (chain mode) where many rows tie exactly: duplicates of one row planted across tiles that
+    different lanes / workgroups own -- the final list must be the lowest ids, in order."""
+    q, c = _case(400_000, 384, 8, seed=1)
+    c = c.copy()
+    full0 = c.astype(np.float32) @ q[0].astype(np.float32)
+    best = int(full0.argmax())
+    planted = sorted({best, 7, 33, 64, 4097, 100_003, 100_035, 250_000, 250_001, 399_999, 123_456, 50})
+    for pos in planted:
+        c[pos] = c[best]
+    gs, gi = _run(cuda, q, c, 10)
+    assert np.array_equal(gi[0], np.array(planted[:10]))
+    assert (gs[0] == gs[0][0]).all()
+    rs, ri = scan_ref.cosine_topk_ref(q, c, 10, accumulate=np.float64)
+    assert np.mean([scan_ref.recall_at_k(gi[r], ri[r]) for r in range(8)]) > 0.99
