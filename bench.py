@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--streams", type=int, default=32,
                     help="independent query batches in flight on separate HIP streams (1 GPU runs only)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--extra-launches", type=int, default=0,
+                    help="diagnostic: this many extra tiny kernels per step (what does one more launch cost?)")
     ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the per-rank query batch size")
     args = ap.parse_args()
 
@@ -141,6 +143,7 @@ def main():
         def __init__(self):
             self.q_out = torch.empty((qb, dim), dtype=torch.float32, device=dev)
             self.q16 = torch.empty((qb, pd), dtype=torch.float16, device=dev)
+            self.dummy16 = torch.empty((qb, pd), dtype=torch.float16, device=dev)
             self.enc_ws = torch.empty(enc.workspace_bytes(qb, QUERY_TOKENS), dtype=torch.uint8, device=dev)
             self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k, rows), dtype=torch.uint8, device=dev)
             self.out_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
@@ -160,6 +163,8 @@ def main():
             nat.queries_to_f16(q32, slab_type, out=c.q16)
         else:   # pooled embeddings leave the encoder as fp32 and as the scan's fp16 query block
             enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=slab_type)
+        for _ in range(args.extra_launches):
+            nat.queries_to_f16(q32, slab_type, out=c.dummy16)
 
     def seg_scan(c):        # all queries of the step x this rank's shard -> per-shard top-k
         nat.cosine_topk(c.q_all if world > 1 else c.q16, slab, rows, dim, k, slab_type=slab_type, scales=scales,

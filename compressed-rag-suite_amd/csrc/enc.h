@@ -27,6 +27,11 @@ int gemm_rowln_launch(const _Float16* a, const _Float16* w, const float* bias, c
                       const float* b, float eps, int m, int hidden, int k, float* x32, _Float16* x16,
                       hipStream_t stream);
 
+// enc_qkvattn.hip: QKV projection + attention of short sequences (16 / 32 / 64 tokens) in one kernel
+bool qkv_attn_supported(int hidden, int heads, int seq);
+int qkv_attn_launch(const _Float16* x16, const _Float16* w_qkv, const float* b_qkv, const int* lens, _Float16* ctx, int batch,
+                    int seq, int hidden, int heads, hipStream_t stream);
+
 // enc_attn.hip: ctx[T, H] = softmax(QK^T / sqrt(hd) + padding mask) V per (batch, head);
 // qkv is [T, 3H] fp16 (Q | K | V column blocks), lens[b] real tokens per row (right padding).
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,

@@ -26,6 +26,12 @@ namespace {
 
 size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
+bool qa_enabled() {   // CRS_ENC_QKVATTN=0: separate QKV GEMM and attention launches (A/B runs, tests)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRS_ENC_QKVATTN"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 // The fused projection + LayerNorm kernel (enc_rowln.hip) is OFF by default: measured on MI355X it is
 // correct but slower than the pair it replaces (MiniLM, 64 x 16 tokens: forward 0.442 ms against 0.292 ms).
 // A workgroup that owns whole rows must stream all of W itself, and a CU ingests only ~50 B/clk through
@@ -139,11 +145,17 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   const bool fuse_ln = T <= kPanelMaxTokens && rowln_enabled();
   const bool rowln_h = fuse_ln && crs::gemm_rowln_supported(H, H), rowln_f = fuse_ln && crs::gemm_rowln_supported(H, F);
   const bool single_h = panel_h && crs::gemm_panel_chunk(H) == H;   // K = H fits one chunk: fused fp16 epilogues
+  // short sequences in the launch-bound regime: QKV projection + attention as one kernel (enc_qkvattn.hip)
+  const bool fuse_qa = T <= kPanelMaxTokens && qa_enabled() && crs::qkv_attn_supported(H, d->heads, seq);
   for (int li = 0; li < d->layers; ++li) {
     const crs_encoder_layer& L = w->layers[li];
+    if (fuse_qa) {
+      CRS_TRY(crs::qkv_attn_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "qkv + attention");
+    } else {
     if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, qkv, T, 3 * H, H, 0, st), "qkv gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, nullptr, qkv, T, 3 * H, H, 0, st), "qkv gemm");
     CRS_TRY(crs::attention_launch(qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "attention");
+    }
     if (rowln_h) {
       CRS_TRY(crs::gemm_rowln_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out gemm + layernorm 1");
     } else if (panel_h) {

@@ -166,7 +166,8 @@ class EmbeddingModel:
         order = sorted(range(n), key=lambda i: -len(texts[i]))
         for lo in range(0, n, self.batch_size):
             sel = order[lo: lo + self.batch_size]
-            ids, lens = pad_batch([token_ids[i] for i in sel], getattr(self.tokenizer, "pad_id", 0))
+            ids, lens = pad_batch([token_ids[i] for i in sel], getattr(self.tokenizer, "pad_id", 0),
+                                  short_steps=tuple(st for st in (16, 32, 64) if st <= self.shape.max_seq))
             emb = self.model.forward(ids, lens, normalize=bool(self.normalize))
             out[torch.as_tensor(sel, device=out.device)] = emb
         return out

@@ -114,10 +114,18 @@ class HashTokenizer:
         return [self.cls_id] + ids + [self.sep_id]
 
 
-def pad_batch(seqs: Sequence[Sequence[int]], pad_id: int = 0) -> Tuple[np.ndarray, np.ndarray]:
-    """Right-pad to the longest sequence of the batch -> (ids int32 [B, S], lens int32 [B])."""
+def pad_batch(seqs: Sequence[Sequence[int]], pad_id: int = 0, short_steps: Sequence[int] = ()) -> Tuple[np.ndarray, np.ndarray]:
+    """Right-pad to the longest sequence of the batch -> (ids int32 [B, S], lens int32 [B]).
+    `short_steps` (ascending, e.g. (16, 32, 64)): a batch whose longest sequence fits one of them is padded
+    up to it -- the fused short-sequence encoder kernels exist for exactly those lengths; padding is masked
+    by `lens`, so the embeddings do not change."""
     lens = np.array([len(s) for s in seqs], dtype=np.int32)
-    out = np.full((len(seqs), int(lens.max())), pad_id, dtype=np.int32)
+    width = int(lens.max())
+    for step in short_steps:
+        if width <= step:
+            width = step
+            break
+    out = np.full((len(seqs), width), pad_id, dtype=np.int32)
     for r, s in enumerate(seqs):
         out[r, : len(s)] = s
     return out, lens

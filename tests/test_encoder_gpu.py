@@ -143,3 +143,22 @@ def test_fused_projection_layernorm_kernel_in_child_process(cuda):
                         os.path.join(root, "tests", "test_encoder_gpu.py"), "-k", "matches_oracle or golden"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("batch,seq", [(3, 16), (5, 16), (64, 16), (2, 32), (7, 32), (1, 64), (3, 64)])
+def test_fused_qkv_attention_shapes(cuda, batch, seq):
+    """enc_qkvattn.hip (MiniLM-class models, 16 / 32 / 64-token batches): token blocks that are not full,
+    several sequences per block, ragged lengths including 1-token rows -- against the fp32 oracle."""
+    cfg = er.MINILM_L6
+    enc, w = _encoder(cfg, 51, cuda)
+    ids, mask = er.synth_tokens(cfg, batch, seq, seed=52 + batch)
+    rng = np.random.default_rng(batch * 100 + seq)
+    lens = rng.integers(1, seq + 1, size=batch).astype(np.int32)
+    lens[0] = seq
+    if batch > 1:
+        lens[-1] = 1
+    mask = (np.arange(seq)[None, :] < lens[:, None]).astype(np.int32)
+    got = enc.forward(ids, lens).cpu().numpy()
+    ref = er.encode_ref(ids, mask, w, cfg)
+    assert _cos(got, ref).min() > 1 - 2e-4
+    assert np.abs(got - ref).max() < 3e-3

@@ -222,3 +222,15 @@ def test_ir_metrics_match_reference_golden():
             assert ir_eval.f1_at_k(ret, rel, k) == c[f"f@{k}"]
     agg = ir_eval.evaluate_rankings([c["retrieved"] for c in cases], [set(c["relevant"]) for c in cases], ks=(1, 10))
     assert abs(agg["mrr"] - sum(c["mrr"] for c in cases) / 60) < 1e-12 and "f1@10" in agg
+
+
+def test_short_batches_are_padded_to_a_fused_length():
+    from rag.tokenizer import pad_batch
+    ids, lens = pad_batch([[101, 7, 102], [101, 102]], 0, short_steps=(16, 32, 64))
+    assert ids.shape == (2, 16) and lens.tolist() == [3, 2] and (ids[0, 3:] == 0).all()
+    ids, lens = pad_batch([[1] * 40], 0, short_steps=(16, 32, 64))
+    assert ids.shape == (1, 64)
+    ids, lens = pad_batch([[1] * 70], 0, short_steps=(16, 32, 64))
+    assert ids.shape == (1, 70)
+    ids, lens = pad_batch([[1] * 5], 0)
+    assert ids.shape == (1, 5)

@@ -20,7 +20,7 @@ def timeit(fn, n=200):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
-print(f"encoder forward, 1 x 16 tokens: {timeit(lambda: enc.forward(ids, lens, workspace=ws)):.0f} us (a hipGraph replay of the same 44 launches measured 254 vs 266 us: the C++ launch loop is not the bound)")
+print(f"encoder forward, 1 x 16 tokens: {timeit(lambda: enc.forward(ids, lens, workspace=ws)):.0f} us (38 launches; before the QKV+attention fusion 44 launches took 266 us, and a hipGraph replay of those measured 254: the C++ launch loop is not the bound)")
 n, d = 100_000, 384
 slab = torch.zeros((n, nat.padded_dim(d)), dtype=torch.float16, device=dev)
 x = torch.randn((n, d), device=dev); nat.slab_append_f32(x, slab, 0, nat.SLAB_F16)
