@@ -32,6 +32,11 @@ bool qkv_attn_supported(int hidden, int heads, int seq);
 int qkv_attn_launch(const _Float16* x16, const _Float16* w_qkv, const float* b_qkv, const int* lens, _Float16* ctx, int batch,
                     int seq, int hidden, int heads, hipStream_t stream);
 
+// enc_ffn.hip: gelu(x W_up^T + b) W_down^T per 96-wide slice of the intermediate dimension, fp32 partials [ns][T][H]
+int ffn_fused_slices(int hidden, int ffn);   // 0: unsupported shape
+int ffn_fused_launch(const _Float16* x16, const _Float16* w_up, const float* b_up, const _Float16* w_down, float* y32,
+                     int tokens, int hidden, int ffn, hipStream_t stream);
+
 // enc_attn.hip: ctx[T, H] = softmax(QK^T / sqrt(hd) + padding mask) V per (batch, head);
 // qkv is [T, 3H] fp16 (Q | K | V column blocks), lens[b] real tokens per row (right padding).
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,

@@ -26,6 +26,16 @@ namespace {
 
 size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
+// The fused feed-forward kernel (enc_ffn.hip) is OFF by default: parity-green, one launch fewer per layer, but
+// measured slower (MiniLM, 64 x 16 tokens: forward 0.295 ms against 0.274 ms; C2 step 0.168 against 0.156 ms):
+// its two operand fetches cannot overlap (W_down's slice re-uses W_up's LDS), and 16 fp32 partials per row
+// cost the LayerNorm 4x the reads of the split-K path.  CRS_ENC_FFN=1 enables it for experiments.
+bool ffn_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRS_ENC_FFN"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 bool qa_enabled() {   // CRS_ENC_QKVATTN=0: separate QKV GEMM and attention launches (A/B runs, tests)
   static int v = -1;
   if (v < 0) { const char* e = getenv("CRS_ENC_QKVATTN"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -66,6 +76,7 @@ Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
   int split = 1;
   if (use_panel((int)t, (int)f)) split = (int)f / crs::gemm_panel_chunk((int)f);
   if (use_panel((int)t, (int)h) && (int)h / crs::gemm_panel_chunk((int)h) > split) split = (int)h / crs::gemm_panel_chunk((int)h);
+  if (t <= kPanelMaxTokens && crs::ffn_fused_slices((int)h, (int)f) > split) split = crs::ffn_fused_slices((int)h, (int)f);
   l.max_split = split;
   l.x32 = off; off += up256(t * h * 4);
   l.y32 = off; off += up256(t * h * 4 * split);
@@ -147,6 +158,7 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   const bool single_h = panel_h && crs::gemm_panel_chunk(H) == H;   // K = H fits one chunk: fused fp16 epilogues
   // short sequences in the launch-bound regime: QKV projection + attention as one kernel (enc_qkvattn.hip)
   const bool fuse_qa = T <= kPanelMaxTokens && qa_enabled() && crs::qkv_attn_supported(H, d->heads, seq);
+  const int ffn_ns = (T <= kPanelMaxTokens && ffn_enabled()) ? crs::ffn_fused_slices(H, F) : 0;
   for (int li = 0; li < d->layers; ++li) {
     const crs_encoder_layer& L = w->layers[li];
     if (fuse_qa) {
@@ -164,6 +176,11 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
     } else {
       CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
+    }
+    if (ffn_ns) {   // both FFN projections in one launch, F/96 fp32 partials summed by the LayerNorm
+      CRS_TRY(crs::ffn_fused_launch(x16, (const _Float16*)L.w_up, L.b_up, (const _Float16*)L.w_down, y32, T, H, F, st), "ffn");
+      CRS_TRY(crs::layernorm_launch(y32, ffn_ns, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+      continue;
     }
     if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_up, L.b_up, ffn, T, F, H, 1, st), "ffn up gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");

@@ -182,6 +182,7 @@ int layernorm_launch(const float* y, int nsplit, const float* bias, const float*
     case 4: CRS_LN2(PL, 4); break;                                                    \
     case 6: CRS_LN2(PL, 6); break;                                                    \
     case 8: CRS_LN2(PL, 8); break;                                                    \
+    case 16: CRS_LN2(PL, 16); break;                                                  \
     default: return -1;                                                               \
   }
   if (hidden == 384) { CRS_LN(6); } else if (hidden == 768) { CRS_LN(12); } else if (hidden <= 64) { CRS_LN(1); } else { CRS_LN(16); }

@@ -134,13 +134,14 @@ def test_forward_queries_writes_the_scan_query_block(cuda, cfg, slab):
 
 
 def test_fused_projection_layernorm_kernel_in_child_process(cuda):
-    """enc_rowln.hip (projection + bias + residual + LayerNorm in one kernel) is off by default because it
-    measured slower; keep it parity-green: re-run the encoder parity cases with CRS_ENC_ROWLN=1."""
+    """enc_rowln.hip (projection + bias + residual + LayerNorm in one kernel) and enc_ffn.hip (both feed-forward
+    projections in one kernel) are off by default because they measured slower; keep them parity-green:
+    re-run the encoder parity cases with CRS_ENC_ROWLN=1 CRS_ENC_FFN=1."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CRS_ENC_ROWLN="1")
+    env = dict(os.environ, CRS_ENC_ROWLN="1", CRS_ENC_FFN="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        os.path.join(root, "tests", "test_encoder_gpu.py"), "-k", "matches_oracle or golden"],
+                        os.path.join(root, "tests", "test_encoder_gpu.py"), "-k", "matches_oracle or golden or fused_qkv"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
