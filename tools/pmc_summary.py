@@ -13,7 +13,8 @@ for w in ("c2", "c3", "c4", "c5"):
     if os.path.exists(src):
         shutil.copy(src, os.path.join(pr, f"{tag}_bench_{w}.json"))
 for w in ("c2", "c4"):
-    for f in glob.glob(os.path.join(go, f"{tag}_stats_{w}", "**", "*kernel_stats.csv"), recursive=True):
+    found = sorted(glob.glob(os.path.join(go, f"{tag}_stats_{w}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    for f in found[-1:]:   # gpurun merges every call's files into gpurun_out/: keep the newest run only
         rows = list(csv.reader(open(f)))
         with open(os.path.join(pr, f"{tag}_{w}_kernel_stats.csv"), "w", newline="") as fh:
             wr = csv.writer(fh)
@@ -30,7 +31,8 @@ for w in ("c2", "c4"):
     ent = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         vals, ns, name, vg = [], [], None, None
-        for f in glob.glob(os.path.join(go, f"{tag}_pmc_{c}_{w}", "**", "*counter_collection.csv"), recursive=True):
+        found = sorted(glob.glob(os.path.join(go, f"{tag}_pmc_{c}_{w}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        for f in found[-1:]:
             for r in csv.DictReader(open(f)):
                 m = scan_pat.search(r["Kernel_Name"])
                 if not m or r["Counter_Name"] != c: continue
