@@ -43,6 +43,95 @@ __device__ __forceinline__ void ln_store(float (&v)[PL], int hidden, int lane, c
   }
 }
 
+// ---- float2 forms (hidden a multiple of 128): a lane owns columns 128 i + 2 lane + {0, 1}.  These kernels are
+// bound by vector-memory ISSUE, not bytes -- a wave pays ~100 cycles per load/store instruction whatever its
+// width, and the 4-byte form needs 48 of them per token at four split-K partials -- so 8 bytes per lane
+// halves their time on the retrieve path (16 bytes would leave a third of the lanes without work at 384).
+template <int P2>
+__device__ __forceinline__ void ln_store2(float (&v)[P2][2], int hidden, int lane, const float* g, const float* b,
+                                          float eps, float* x32, _Float16* x16) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < P2; ++i) s += v[i][0] + v[i][1];
+  const float mean = wave_sum(s) / hidden;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {
+    const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+    q += d0 * d0 + d1 * d1;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / hidden + eps);
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {
+    const int c = 128 * i + 2 * lane;
+    const float2 gg = *reinterpret_cast<const float2*>(g + c), bb = *reinterpret_cast<const float2*>(b + c);
+    float2 o;
+    o.x = (v[i][0] - mean) * rstd * gg.x + bb.x;
+    o.y = (v[i][1] - mean) * rstd * gg.y + bb.y;
+    *reinterpret_cast<float2*>(x32 + c) = o;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 h = {(_Float16)o.x, (_Float16)o.y};
+    *reinterpret_cast<h2*>(x16 + c) = h;
+  }
+}
+
+template <int P2>
+__global__ __launch_bounds__(256) void embed_ln2_kernel(const int* __restrict__ ids, const float* __restrict__ word,
+                                                       const float* __restrict__ pos, const float* __restrict__ type0,
+                                                       const float* __restrict__ g, const float* __restrict__ b,
+                                                       float eps, int tokens, int seq, int hidden, int vocab,
+                                                       float* __restrict__ x32, _Float16* __restrict__ x16) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= tokens) return;
+  int id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* w = word + (size_t)id * hidden;
+  const float* p = pos + (size_t)(t % seq) * hidden;
+  float v[P2][2];
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {
+    const int c = 128 * i + 2 * lane;
+    const float2 a = *reinterpret_cast<const float2*>(w + c), ty = *reinterpret_cast<const float2*>(type0 + c),
+                 pp = *reinterpret_cast<const float2*>(p + c);
+    v[i][0] = (a.x + ty.x) + pp.x;   // (word + token_type) + position, as modeling_bert
+    v[i][1] = (a.y + ty.y) + pp.y;
+  }
+  ln_store2<P2>(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
+}
+
+template <int P2, int NS>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                        const float* residual,   // may alias x32 (in place)
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        float eps, int tokens, int hidden, float* x32,
+                                                        _Float16* __restrict__ x16) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= tokens) return;
+  const float* src = y + (size_t)t * hidden;
+  const size_t split_stride = (size_t)tokens * hidden;
+  float2 part[NS][P2], extra[2][P2];
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {
+    const int c = 128 * i + 2 * lane;
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) part[sidx][i] = *reinterpret_cast<const float2*>(src + sidx * split_stride + c);
+    extra[0][i] = bias ? *reinterpret_cast<const float2*>(bias + c) : float2{0.f, 0.f};
+    extra[1][i] = residual ? *reinterpret_cast<const float2*>(residual + (size_t)t * hidden + c) : float2{0.f, 0.f};
+  }
+  float v[P2][2];
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {
+    float a0 = part[0][i].x, a1 = part[0][i].y;
+#pragma unroll
+    for (int sidx = 1; sidx < NS; ++sidx) { a0 += part[sidx][i].x; a1 += part[sidx][i].y; }
+    v[i][0] = (a0 + extra[0][i].x) + extra[1][i].x;
+    v[i][1] = (a1 + extra[0][i].y) + extra[1][i].y;
+  }
+  ln_store2<P2>(v, hidden, lane, g, b, eps, x32 + (size_t)t * hidden, x16 + (size_t)t * hidden);
+}
+
 template <int PL>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const float* __restrict__ word,
                                                       const float* __restrict__ pos, const float* __restrict__ type0,
@@ -164,7 +253,10 @@ int embed_ln_launch(const int* ids, const float* word, const float* pos, const f
                     _Float16* x16, hipStream_t stream) {
 #define CRS_EMB(PL) hipLaunchKernelGGL((embed_ln_kernel<PL>), dim3((tokens + 3) / 4), dim3(256), 0, stream, ids, word, \
                                       pos, type0, g, b, eps, tokens, seq, hidden, vocab, x32, x16)
-  if (hidden == 384) CRS_EMB(6); else if (hidden == 768) CRS_EMB(12); else if (hidden <= 64) CRS_EMB(1); else CRS_EMB(16);
+#define CRS_EMB2(P2) hipLaunchKernelGGL((embed_ln2_kernel<P2>), dim3((tokens + 3) / 4), dim3(256), 0, stream, ids, word, \
+                                       pos, type0, g, b, eps, tokens, seq, hidden, vocab, x32, x16)
+  if (hidden == 384) CRS_EMB2(3); else if (hidden == 768) CRS_EMB2(6); else if (hidden <= 64) CRS_EMB(1); else CRS_EMB(16);
+#undef CRS_EMB2
 #undef CRS_EMB
   return (int)hipGetLastError();
 }
@@ -185,7 +277,22 @@ int layernorm_launch(const float* y, int nsplit, const float* bias, const float*
     case 16: CRS_LN2(PL, 16); break;                                                  \
     default: return -1;                                                               \
   }
-  if (hidden == 384) { CRS_LN(6); } else if (hidden == 768) { CRS_LN(12); } else if (hidden <= 64) { CRS_LN(1); } else { CRS_LN(16); }
+#define CRS_LNV2(P2, NS) hipLaunchKernelGGL((layernorm2_kernel<P2, NS>), dim3((tokens + 3) / 4), dim3(256), 0, stream, y, \
+                                          bias, residual, g, b, eps, tokens, hidden, x32, x16)
+#define CRS_LNV(P2)                                                                   \
+  switch (nsplit) {                                                                   \
+    case 1: CRS_LNV2(P2, 1); break;                                                   \
+    case 2: CRS_LNV2(P2, 2); break;                                                   \
+    case 3: CRS_LNV2(P2, 3); break;                                                   \
+    case 4: CRS_LNV2(P2, 4); break;                                                   \
+    case 6: CRS_LNV2(P2, 6); break;                                                   \
+    case 8: CRS_LNV2(P2, 8); break;                                                   \
+    case 16: CRS_LNV2(P2, 16); break;                                                 \
+    default: return -1;                                                               \
+  }
+  if (hidden == 384) { CRS_LNV(3); } else if (hidden == 768) { CRS_LNV(6); } else if (hidden <= 64) { CRS_LN(1); } else { CRS_LN(16); }
+#undef CRS_LNV
+#undef CRS_LNV2
 #undef CRS_LN
 #undef CRS_LN2
   return (int)hipGetLastError();
