@@ -188,6 +188,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
 // by the LayerNorm kernel that follows anyway (enc_misc.hip), so no extra pass or atomics exist.
 // LDS image: rows of kc halves, 16-byte chunks XOR-swizzled by row inside each 256-byte group;
 // the DMA writes LDS linearly, so the swizzle is applied to the per-lane SOURCE address.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int PN = 64, PKC = 384;
 
 // MODE 0: +bias -> fp16; 1: +bias, GELU -> fp16; 3: raw fp32 partial tile -> out[z][M][N].
@@ -233,37 +234,77 @@ __global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Flo
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (wave >= kTiles) return;   // TM = 64: waves 4..7 only helped fetching
+  const bool computes = wave < kTiles;   // TM = 64: waves 4..7 only help fetching
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int fr = lane & 31, fh = lane >> 5;
-  const int arow = wm * 32 + fr, wrow = wn * 32 + fr;
-  const char* pa = sa + arow * (cpr * 16);
-  const char* pw = sw + wrow * (cpr * 16);
-  const int ksteps = kc >> 4;
+  if (computes) {
+    const int arow = wm * 32 + fr, wrow = wn * 32 + fr;
+    const char* pa = sa + arow * (cpr * 16);
+    const char* pw = sw + wrow * (cpr * 16);
+    const int ksteps = kc >> 4;
 #pragma unroll 4
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int c = ks * 2 + fh;
-    const f16x8 af = *reinterpret_cast<const f16x8*>(pa + (((c & ~15) | ((c ^ arow) & 15)) << 4));
-    const f16x8 bf = *reinterpret_cast<const f16x8*>(pw + (((c & ~15) | ((c ^ wrow) & 15)) << 4));
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int c = ks * 2 + fh;
+      const f16x8 af = *reinterpret_cast<const f16x8*>(pa + (((c & ~15) | ((c ^ arow) & 15)) << 4));
+      const f16x8 bf = *reinterpret_cast<const f16x8*>(pw + (((c & ~15) | ((c ^ wrow) & 15)) << 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    }
   }
+  __syncthreads();   // every fragment read done: the panels' LDS becomes the waves' output tiles
+  if (!computes) return;
 
+  // Epilogue through a wave-private LDS tile so that a lane stores 16 bytes of one row: 4 (fp32) or 2 (fp16)
+  // store instructions per 32 x 32 tile instead of 16 -- a vector-memory instruction costs the wave ~100
+  // cycles of issue whatever its width, and these kernels are latency chains, not bandwidth.
   const int col = n0 + wn * 32 + fr;
-  if (col < N) {
-    const float b = (MODE != 3 && bias) ? bias[col] : 0.f;
+  const float b = (MODE != 3 && bias && col < N) ? bias[col] : 0.f;
+  const int c0 = n0 + wn * 32, r0 = m0 + wm * 32;
+  if (MODE == 3) {
+    constexpr int TS = 36;   // floats per tile row (144 bytes: 16-byte aligned, bank-spread)
+    float* my = reinterpret_cast<float*>(psm) + wave * (32 * TS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * fh) * TS + fr] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+    float* o = reinterpret_cast<float*>(out) + (size_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lrow = q * 8 + (lane >> 3), lc = (lane & 7) * 4;
+      const int row = r0 + lrow;
+      if (row >= M) continue;
+      const f32x4v v = *reinterpret_cast<const f32x4v*>(&my[lrow * TS + lc]);
+      float* dst = o + (size_t)row * N + c0 + lc;
+      if (c0 + lc + 3 < N && (N & 3) == 0) {
+        *reinterpret_cast<f32x4v*>(dst) = v;
+      } else {
+        for (int e = 0; e < 4 && c0 + lc + e < N; ++e) dst[e] = v[e];
+      }
+    }
+  } else {
+    constexpr int TS = 40;   // halves per tile row (80 bytes)
+    _Float16* my = reinterpret_cast<_Float16*>(psm) + wave * (32 * TS);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (row >= M) continue;
       float v = acc[r] + b;
       if (MODE == 1) v = gelu_erf(v);
-      if (MODE == 3)
-        reinterpret_cast<float*>(out)[((size_t)blockIdx.z * M + row) * N + col] = v;
-      else
-        reinterpret_cast<_Float16*>(out)[(size_t)row * N + col] = (_Float16)v;
+      my[((r & 3) + 8 * (r >> 2) + 4 * fh) * TS + fr] = (_Float16)v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int lrow = q * 16 + (lane >> 2), lc = (lane & 3) * 8;
+      const int row = r0 + lrow;
+      if (row >= M) continue;
+      const f16x8 h = *reinterpret_cast<const f16x8*>(&my[lrow * TS + lc]);
+      _Float16* dst = o + (size_t)row * N + c0 + lc;
+      if (c0 + lc + 7 < N && (N & 7) == 0) {
+        *reinterpret_cast<f16x8*>(dst) = h;
+      } else {
+        for (int e = 0; e < 8 && c0 + lc + e < N; ++e) dst[e] = h[e];
+      }
     }
   }
 }
