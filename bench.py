@@ -297,11 +297,23 @@ def main():
                 break
     except Exception:
         pass
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+    # Which roof bounds the launch: flop per algorithmic byte (= queries per launch for fp16, 2x that for int8)
+    # against the ridge of the dense MFMA peak over the HBM peak (MI355X_MICROARCH.md: 2.5 PF fp16 / 5 PF int8, 8 TB/s).
+    # One rank of an N-GPU step scans its shard for the queries of ALL ranks, so from ~313 queries on the scan is
+    # matrix-bound and is priced against the MFMA peak; both fractions are reported either way.
+    alg_flops = 2.0 * nq_all * rows * pd
+    mfma_peak_tf = 5000.0 if slab_type == nat.SLAB_I8 else 2500.0
+    achieved_tf = alg_flops / (ms_scan * 1e-3) / 1e12
+    hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, achieved_tf / mfma_peak_tf
+    mfma_bound = (alg_flops / alg_bytes) > (mfma_peak_tf * 1e12) / (HBM_PEAK_GBS * 1e9)
+    roofline = {"bound": "mfma" if mfma_bound else "hbm",
+                "achieved": round(achieved_tf if mfma_bound else achieved, 1),
+                "peak": mfma_peak_tf if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": round(mfma_frac if mfma_bound else hbm_frac, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": nat.scan_plan_describe(nq_all, dim, k, rows, slab_type),
                 "kernel_ms": round(ms_scan, 5), "scan_plus_merge_ms": round(ms_total, 5),
-                "algorithmic_bytes": int(alg_bytes)}
+                "algorithmic_bytes": int(alg_bytes), "algorithmic_flops": int(alg_flops),
+                "hbm_frac": round(hbm_frac, 4), "mfma_frac": round(mfma_frac, 4)}
 
     # ---- correctness of the timed result + CPU baseline (rank 0, N=1 only): the oracle, same workload
     cpu = None

@@ -76,7 +76,7 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   p->tb_nw = 0;
   if (!p->wide_nw && slab_type == CRS_SLAB_F16 && k <= 16 && tb_enabled())
     p->tb_nw = (nq > 64 && crs::scan_tb_has_8_waves(p->pdim)) ? 8 : 4;
-  p->tile_rows = p->wide_nw ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
+  p->tile_rows = p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
   const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim)
                          : p->tb_nw ? crs::scan_tb_wg_per_cu(p->pdim, p->tb_nw) : crs::scan_wg_per_cu());

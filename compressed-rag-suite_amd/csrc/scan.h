@@ -24,7 +24,7 @@ struct ScanArgs {
   int nqb;                // query blocks (64, 128 or 256 queries each); the grid is nqb * nwg workgroups (scan_common.h: grid mapping)
 };
 
-// scan_refine.hip: re-open the k winning tiles (16 or 32 rows each) per query, re-score, rank
+// scan_refine.hip: re-open the k winning tiles (16, 32 or 64 rows each) per query, re-score, rank
 int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, int n_rows, const float* win_s,
                   const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream);
 
@@ -44,6 +44,7 @@ int scan_launch_tb(const ScanArgs& a, int pdim, int nw, int slots, hipStream_t s
 int scan_wide_waves(int nq, int k, int pdim);
 int scan_wide_wg_per_cu(int nw, int pdim);
 int scan_wide_slots(int k);
+int scan_wide_tile_rows(int nw, int pdim);
 int scan_launch_wide(const ScanArgs& a, int pdim, int nw, hipStream_t stream);
 
 // merge.hip

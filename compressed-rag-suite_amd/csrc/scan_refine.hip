@@ -8,8 +8,8 @@
 //   score(y_i) = best(Y_i) > best(X) >= score(x), or with score(y_i) = best(X) >= score(x) and Y_i < X,
 //   i.e. row(y_i) < row(x) because tiles are contiguous row ranges -- k distinct rows beat x, a
 //   contradiction.  Hence the k best tiles contain every top-k row, and no arg-max is ever needed.
-// This kernel re-opens those k tiles per query (16 or 32 rows each), re-scores their rows with the scan's
-// own arithmetic (v_mfma_f32_16x16x32_f16, same k-chunk order) and ranks the <= 512 candidates by
+// This kernel re-opens those k tiles per query (16, 32 or 64 rows each), re-scores their rows with the scan's
+// own arithmetic (v_mfma_f32_16x16x32_f16, same k-chunk order) and ranks the (<= 1024, typically ~k) candidates by
 // counting: one 16-wave workgroup per query, the final sorted (score desc, row asc) top-k comes out directly.
 
 #include "scan.h"
@@ -32,8 +32,8 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
                                                             const int64_t* __restrict__ win, int k, int tile_rows, int64_t id_base, float* __restrict__ out_s,
                                                             int64_t* __restrict__ out_i) {
   constexpr int kKs = D / 32;
-  __shared__ float cs[512];
-  __shared__ int ci[512];
+  __shared__ float cs[1024];   // k * tile_rows <= 16 * 64
+  __shared__ int ci[1024];
   __shared__ int cnt;
   const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
   if (tid == 0) cnt = 0;
   for (int r = tid; r < k; r += kRefThreads) { out_s[(size_t)q * k + r] = kNegInfR; out_i[(size_t)q * k + r] = -1; }
 
-  const int halves = tile_rows / 16;          // 16-row MFMA blocks per tile: 1 or 2
-  const int units = k * halves;               // <= 32
+  const int halves = tile_rows / 16;          // 16-row MFMA blocks per tile: 1, 2 or 4
+  const int units = k * halves;               // <= 64
   // Only rows scoring >= the k-th best tile representative can reach the final top-k (that score is
   // attained by k distinct rows already), so the ranking below sees ~k candidates, not k * tile_rows.
   // (a hair below it: scan_wide.hip forms the same dot products with the 32x32x16 MFMA shape, and nothing
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
       for (int ii = 0; ii < 4; ++ii) {
         const int rr = first + 4 * kq + ii;
         if (rr < n_rows && acc[ii] >= tau) {
-          const int p = atomicAdd(&cnt, 1);   // p < units * 16 <= 512 by construction
+          const int p = atomicAdd(&cnt, 1);   // p < units * 16 <= 1024 by construction
           cs[p] = acc[ii];
           ci[p] = rr;
         }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
 
 int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, int n_rows, const float* win_s,
                   const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream) {
-  if (k > 16 || (tile_rows != 16 && tile_rows != 32)) return -1;
+  if (k > 16 || (tile_rows != 16 && tile_rows != 32 && tile_rows != 64)) return -1;
 #define CRS_REFINE(DD) hipLaunchKernelGGL((refine_kernel<DD>), dim3(nq), dim3(kRefThreads), 0, stream, q16, slab, n_rows, win_s, win, k, tile_rows, \
                                          id_base, out_s, out_i)
   switch (pdim) {

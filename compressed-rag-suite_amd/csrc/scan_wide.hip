@@ -52,13 +52,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WP_STORE(nw_) do {} while (0)
 #endif
 
-constexpr int WTR = 32;   // tile rows = one 32x32 MFMA row block
+
+// rows per tile: 32 * RB (RB 32x32 MFMA row blocks).  The 8-wave kernel takes 64-row tiles where the registers
+// allow: the per-tile costs that are not MFMAs (barrier, selection chain, load issue, LDS store: ~1.9 k cycles
+// per wave and 32-row tile against 1.5 k of matrix work) are then paid once per 64 rows.
+template <int D, int NW>
+constexpr int wide_rb() { return (NW == 8 && D <= 384) ? 2 : 1; }
 
 template <int D, int NW>
 struct WCfg {
   static constexpr int kThreadsW = NW * 64;
   static constexpr int kCpr = D / 8;
-  static constexpr int kTileBytes = WTR * D * 2;
+  static constexpr int RB = wide_rb<D, NW>();
+  static constexpr int TR = 32 * RB;
+  static constexpr int kTileBytes = TR * D * 2;
   static constexpr int kLoads = kTileBytes / (kThreadsW * 16);
   static constexpr int kKsteps = D / 16;
   static constexpr int kLds = 2 * kTileBytes;
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
   }
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
+  constexpr int RB = C::RB, WTR = C::TR;
   const int n_full = a.n_rows / WTR;
 
   // Two register staging sets: while tile i is being multiplied out of LDS, tiles i+1 AND i+2 are in
@@ -199,36 +207,50 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
   // both in the VALU selection with the matrix pipe idle -- measured 3.7 k cycles per tile against 1.5 k
   // of MFMA work.  So waves 4..7 defer the selection of a tile by one iteration (its 16 accumulators stay
   // in registers across the barrier): on every SIMD one wave multiplies while the other selects.
-  const bool late = (NW == 8 && D <= 384) && wave >= 4;   // wave-uniform (D = 512: no registers left for it)
-  f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto sweep = [&](const char* buf) {
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool late = (NW == 8 && D <= 384 && !(D == 384 && K == 16)) && wave >= 4;   // wave-uniform; off where the
+                                                                                      // deferred accumulators would spill
+  struct Acc { f32x16 a[RB]; };
+  Acc acc_prev;
 #pragma unroll
-    for (int ks = 0; ks < C::kKsteps; ++ks) {
-      const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 7] + (ks >> 3) * 256);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[ks], acc, 0, 0, 0);
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_prev.a[rb][r] = 0.f;
+  auto sweep = [&](const char* buf) {
+    Acc acc;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc.a[rb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::kKsteps; ++ks) {
+        const f16x8 af = *reinterpret_cast<const f16x8*>(buf + rb * 32 * (C::kCpr * 16) + a_off[ks & 7] + (ks >> 3) * 256);
+        acc.a[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[ks], acc.a[rb], 0, 0, 0);
+      }
     }
     return acc;
   };
   // tile te (the ie-th of this stream): the tile's best score for this lane's query -> sorted list.
   // The representative is (best score, first row of the tile): tiles are contiguous row ranges, so on
   // equal scores the lower tile holds the lower rows and no arg-max is needed (scan_refine.hip).
-  auto select = [&](const f32x16& acc, int te, int ie) {
-    float x;
-    if (te < n_full) {
-      const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
-      const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
-      const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
-      const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
-      const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
-      x = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)), __builtin_fmaxf(m4, acc[15]));
-    } else {   // ragged last tile: rows past the end must not win
-      x = kNegInf;
-      const int row_base = te * WTR + 4 * h;
+  auto select = [&](const Acc& accs, int te, int ie) {
+    float x = kNegInf;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row_base + 8 * (r >> 2) + (r & 3);
-        x = (row < a.n_rows) ? __builtin_fmaxf(x, acc[r]) : x;
+    for (int rb = 0; rb < RB; ++rb) {
+      const f32x16& acc = accs.a[rb];
+      if (te < n_full) {
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+        const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+        const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+        x = __builtin_fmaxf(x, __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)), __builtin_fmaxf(m4, acc[15])));
+      } else {   // ragged last tile: rows past the end must not win
+        const int row_base = te * WTR + rb * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + 8 * (r >> 2) + (r & 3);
+          x = (row < a.n_rows) ? __builtin_fmaxf(x, acc[r]) : x;
+        }
       }
     }
     x = pair_max(x);                              // both halves: the tile's best
@@ -248,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
       WP_LAP(1);   // tile-load issue
       const char* buf = tile_buf + cur * C::kTileBytes;
       if (!late) {
-        f32x16 acc = sweep(buf);
+        const Acc acc = sweep(buf);
         WP_LAP(3);   // MFMA sweep
         select(acc, t, it);
       } else {       // waves 4..7: last tile's selection first, then this tile's MFMAs
@@ -333,6 +355,8 @@ int scan_wide_waves(int nq, int k, int pdim) {
   if (!on || nq <= 64 || k > 16 || pdim > 512) return 0;
   return nq > 128 ? 8 : 4;
 }
+// rows per tile of the configuration scan_wide_waves() picks
+int scan_wide_tile_rows(int nw, int pdim) { return (nw == 8 && pdim <= 384) ? 64 : 32; }
 // list slots per lane the kernel is instantiated for (>= k); the partial lists are 2 * this wide
 int scan_wide_slots(int k) { return k <= 4 ? 4 : k <= 10 ? 10 : 16; }
 // resident workgroups per CU: the query fragments cost D/4 registers per lane -> two waves per SIMD

@@ -16,7 +16,8 @@ int main(int argc, char** argv) {
   const int k = argc > 4 ? atoi(argv[4]) : 10;
   const int nw = crs::scan_wide_waves(nq, k, dim);
   if (!nw) { printf("wide kernel not applicable\n"); return 1; }
-  const int n_tiles = (rows + 31) / 32;
+  const int tile_rows = crs::scan_wide_tile_rows(nw, dim);
+  const int n_tiles = (rows + tile_rows - 1) / tile_rows;
   hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
   const int nqb = (nq + 32 * nw - 1) / (32 * nw);
   int nwg = prop.multiProcessorCount * crs::scan_wide_wg_per_cu(nw, dim) / nqb;
