@@ -42,6 +42,7 @@ struct Plan {
   int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
   int nqb;                                 // query blocks (64 queries each; 32 * wide_nw for the wide kernel)
   int wide_nw;                             // > 0: scan_wide.hip with this many waves per workgroup
+  int wide_ks;                             // 1: scan_wide_ks.hip (768 / 1024-element rows, 128 queries per workgroup)
   int tb_nw;                               // > 0: scan_tb.hip with this many waves per workgroup
   int tb_slots;                            //   its chain length (0: dump mode)
   int group_best;                          // 1: the scan leaves tile representatives (scan_refine.hip finishes)
@@ -73,15 +74,16 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   p->pdim = crs_row_elems(dim, slab_type);
   // kernel family: classic threshold/compaction scan (k > 16, int8), or one of the tile-best kernels
   p->wide_nw = slab_type == CRS_SLAB_F16 ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
+  p->wide_ks = (!p->wide_nw && slab_type == CRS_SLAB_F16 && crs::scan_wide_ks_applies(nq, k, p->pdim)) ? 1 : 0;
   p->tb_nw = 0;
-  if (!p->wide_nw && slab_type == CRS_SLAB_F16 && k <= 16 && tb_enabled())
+  if (!p->wide_nw && !p->wide_ks && slab_type == CRS_SLAB_F16 && k <= 16 && tb_enabled())
     p->tb_nw = (nq > 64 && crs::scan_tb_has_8_waves(p->pdim)) ? 8 : 4;
-  p->tile_rows = p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
+  p->tile_rows = p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : p->wide_ks ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
-  const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim)
+  const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim) : p->wide_ks ? 1
                          : p->tb_nw ? crs::scan_tb_wg_per_cu(p->pdim, p->tb_nw) : crs::scan_wg_per_cu());
   // all query blocks of a tile stream must be co-resident: streams = resident slots / query blocks
-  const int qpb = p->wide_nw ? 32 * p->wide_nw : p->tb_nw ? 16 * p->tb_nw : 64;
+  const int qpb = p->wide_nw ? 32 * p->wide_nw : p->wide_ks ? 128 : p->tb_nw ? 16 * p->tb_nw : 64;
   const int nqb = (nq + qpb - 1) / qpb;
   p->nqb = nqb;
   int streams = cap / nqb;
@@ -92,7 +94,7 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   p->kp = partial_width(k);
   p->group_best = 0;
   p->tb_slots = 0;
-  if (p->wide_nw) {                        // register chain of the K best tile representatives per lane
+  if (p->wide_nw || p->wide_ks) {          // register chain of the K best tile representatives per lane
     p->kp = 2 * crs::scan_wide_slots(k);
     p->group_best = 1;
   } else if (p->tb_nw) {
@@ -206,6 +208,7 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.nwg = p.nwg;
   a.nqb = p.nqb;
   const int e = p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
+                : p.wide_ks ? crs::scan_launch_wide_ks(a, p.pdim, st)
                 : (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
                 : p.tb_nw ? crs::scan_launch_tb(a, p.pdim, p.tb_nw, p.tb_slots, st)
                                : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
@@ -276,6 +279,7 @@ int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type
   if (rc) return rc;
   char name[96];
   if (p.wide_nw) snprintf(name, sizeof name, "scan_wide_kernel<%d,%d,%d>", p.pdim, p.wide_nw, crs::scan_wide_slots(k));
+  else if (p.wide_ks) snprintf(name, sizeof name, "scan_wide_ks_kernel<%d,%d>", p.pdim, crs::scan_wide_slots(k));
   else if (p.tb_nw) snprintf(name, sizeof name, "scan_tb_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, p.tb_nw, p.tb_slots);
   else if (slab_type == CRS_SLAB_I8) snprintf(name, sizeof name, "scan_i8_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
   else snprintf(name, sizeof name, "scan_f16_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
