@@ -43,6 +43,7 @@ struct Plan {
   int nqb;                                 // query blocks (64 queries each; 32 * wide_nw for the wide kernel)
   int wide_nw;                             // > 0: scan_wide.hip with this many waves per workgroup
   int wide_ks;                             // 1: scan_wide_ks.hip (768 / 1024-element rows, 128 queries per workgroup)
+  int i8_tb;                               // 1: scan_i8.hip in a tile-best mode (tb_slots: 0 dump, else chain)
   int tb_nw;                               // > 0: scan_tb.hip with this many waves per workgroup
   int tb_slots;                            //   its chain length (0: dump mode)
   int group_best;                          // 1: the scan leaves tile representatives (scan_refine.hip finishes)
@@ -78,6 +79,7 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   p->tb_nw = 0;
   if (!p->wide_nw && !p->wide_ks && slab_type == CRS_SLAB_F16 && k <= 16 && tb_enabled())
     p->tb_nw = (nq > 64 && crs::scan_tb_has_8_waves(p->pdim)) ? 8 : 4;
+  p->i8_tb = (slab_type == CRS_SLAB_I8 && k <= 16 && tb_enabled()) ? 1 : 0;   // scan_i8.hip's tile-best modes
   p->tile_rows = p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : p->wide_ks ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
   p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
   const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim) : p->wide_ks ? 1
@@ -97,7 +99,7 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   if (p->wide_nw || p->wide_ks) {          // register chain of the K best tile representatives per lane
     p->kp = 2 * crs::scan_wide_slots(k);
     p->group_best = 1;
-  } else if (p->tb_nw) {
+  } else if (p->tb_nw || p->i8_tb) {
     // short streams: every tile's representative goes straight to the partial list ("dump"; merge.hip's
     // single-pass path takes <= 8192 candidates per query); longer ones keep the K best in registers
     const int tps = (p->n_tiles + p->nwg - 1) / p->nwg;
@@ -209,7 +211,7 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.nqb = p.nqb;
   const int e = p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
                 : p.wide_ks ? crs::scan_launch_wide_ks(a, p.pdim, st)
-                : (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.nwg, st)
+                : (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.i8_tb ? p.tb_slots : -1, st)
                 : p.tb_nw ? crs::scan_launch_tb(a, p.pdim, p.tb_nw, p.tb_slots, st)
                                : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
   *ps_out = ps;
@@ -246,8 +248,11 @@ int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const v
   int64_t* win_i = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(win_s) + align_up((size_t)nq * k * 4, 256));
   e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, 0, win_s, win_i, st);
   if (e) return hip_fail((hipError_t)e, "merge launch");
-  e = crs::refine_launch(reinterpret_cast<const _Float16*>(q16_dev), nq, p.pdim, reinterpret_cast<const _Float16*>(slab_dev),
-                         (int)n_rows, win_s, win_i, k, p.tile_rows, id_base, out_scores_dev, out_ids_dev, st);
+  e = (slab_type == CRS_SLAB_I8)
+          ? crs::refine_i8_launch(reinterpret_cast<const _Float16*>(q16_dev), nq, p.pdim, slab_dev, scales_dev, (int)n_rows, win_s,
+                                  win_i, k, p.tile_rows, id_base, out_scores_dev, out_ids_dev, st)
+          : crs::refine_launch(reinterpret_cast<const _Float16*>(q16_dev), nq, p.pdim, reinterpret_cast<const _Float16*>(slab_dev),
+                               (int)n_rows, win_s, win_i, k, p.tile_rows, id_base, out_scores_dev, out_ids_dev, st);
   if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
   if (e) return hip_fail((hipError_t)e, "refine launch");
   return CRS_OK;
@@ -281,7 +286,7 @@ int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type
   if (p.wide_nw) snprintf(name, sizeof name, "scan_wide_kernel<%d,%d,%d>", p.pdim, p.wide_nw, crs::scan_wide_slots(k));
   else if (p.wide_ks) snprintf(name, sizeof name, "scan_wide_ks_kernel<%d,%d>", p.pdim, crs::scan_wide_slots(k));
   else if (p.tb_nw) snprintf(name, sizeof name, "scan_tb_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, p.tb_nw, p.tb_slots);
-  else if (slab_type == CRS_SLAB_I8) snprintf(name, sizeof name, "scan_i8_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
+  else if (slab_type == CRS_SLAB_I8) snprintf(name, sizeof name, "scan_i8_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32, p.i8_tb ? p.tb_slots : -1);
   else snprintf(name, sizeof name, "scan_f16_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
   snprintf(buf, cap, "%s streams=%d qblocks=%d kp=%d + merge%s", name, p.nwg, p.nqb, p.kp, p.group_best ? " + refine" : "");
   return CRS_OK;

@@ -28,13 +28,17 @@ struct ScanArgs {
 int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, int n_rows, const float* win_s,
                   const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream);
 
+int refine_i8_launch(const _Float16* q16, int nq, int pdim, const void* slab, const float* scales, int n_rows, const float* win_s,
+                     const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream);
+
 int scan_tile_rows(int pdim);
 int scan_i8_tile_rows();
 int scan_wg_per_cu();    // resident workgroups per CU the active scan.hip variant is launched with
 bool scan_share_tau();  // CRS_SCAN_SHARE_TAU=1 enables cross-workgroup threshold sharing (scan.hip; measured slower, off)
 // returns hipError_t as int, -1 for an unsupported padded dimension
 int scan_launch_f16(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
-int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream);
+// slots: -1 threshold kernel; 0 tile-best dump; 4 / 10 / 16 tile-best chain (finished by merge + refine_i8_launch)
+int scan_launch_i8(const ScanArgs& a, int pdim, int slots, hipStream_t stream);
 // scan_tb.hip: tile-best 16x16x32 scan, k <= 16; nw = 4 (64 queries / workgroup) or 8 (128);
 // slots = 0: dump mode (kp = tiles per stream), else chain mode (kp = slots); finished by merge + refine_launch
 int scan_tb_wg_per_cu(int pdim, int nw);

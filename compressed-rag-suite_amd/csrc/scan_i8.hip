@@ -39,7 +39,10 @@ struct CfgI8 {
   static_assert(kTileBytes % (kThreads * 16) == 0, "tile must split into whole 16-byte loads");
 };
 
-template <int D, int TR, int L>
+// TBK = -1: threshold + LDS lists + compaction (k > 16).  TBK >= 0: tile-best selection as in scan_tb.hip --
+// 0 "dump" (short streams: every tile's best score goes to the partial list), > 0 "chain" (that many
+// register-resident slots); scan_refine.hip's int8 kernel re-opens the winning tiles.
+template <int D, int TR, int L, int TBK>
 __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) {
   using C = CfgI8<D, TR, L>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -179,8 +182,30 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
 
   float tau = q_valid ? kNegInf : __builtin_huge_valf();
   int cnt = 0;
-  unsigned* tau_pub = (a.tau_shared && q_valid) ? a.tau_shared + qi : nullptr;
+  unsigned* tau_pub = (TBK < 0 && a.tau_shared && q_valid) ? a.tau_shared + qi : nullptr;
   unsigned tg = 0;
+  // tile-best state (TBK >= 0): see scan_tb.hip
+  constexpr int KK = TBK > 0 ? TBK : 1;
+  float ts[KK];
+  int tr[KK];
+#pragma unroll
+  for (int j = 0; j < KK; ++j) { ts[j] = kNegInf; tr[j] = -1; }
+  float px = kNegInf;
+  int pr = -1;
+  int it = 0;
+  auto insert = [&](float x, int xr) {
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      const bool c = x > ts[j];
+      const float s_old = ts[j];
+      const int r_old = tr[j];
+      ts[j] = c ? x : s_old;
+      tr[j] = c ? xr : r_old;
+      x = c ? s_old : x;
+      xr = c ? r_old : xr;
+    }
+  };
+  const size_t po = ((size_t)(q_valid ? qi : 0) * nwg + CRS_STREAM) * a.kp;   // this query's partial list [nq, nwg, kp]
 
   park_tile(0);
   __syncthreads();
@@ -198,6 +223,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     }
     if (wave_active) {
       const char* buf = tile_buf + cur * C::kTileBytes;
+      float best = kNegInf;
 #pragma unroll
       for (int rt = 0; rt < C::kRt; ++rt) {
         i32x4 acc_hi = {0, 0, 0, 0}, acc_lo = {0, 0, 0, 0};
@@ -213,13 +239,33 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
         for (int i = 0; i < 4; ++i) {
           const float sc = ((float)acc_hi[i] * 256.0f + (float)acc_lo[i]) * qscale * rsc[i];
           const int row = row0 + i;
-          if (sc > tau && row < a.n_rows) {
+          if constexpr (TBK >= 0) {
+            best = (row < a.n_rows) ? fmaxf(best, sc) : best;
+          } else if (sc > tau && row < a.n_rows) {
             sbuf[cnt * 64 + lane] = sc;
             ibuf[cnt * 64 + lane] = row;
             ++cnt;
           }
         }
-        if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0, tau_pub);
+        if constexpr (TBK < 0) {
+          if (__any(cnt > L - 4)) compact<L, false>(sbuf, ibuf, lane, cnt, tau, a.k, nullptr, nullptr, q_valid, 0, tau_pub);
+        }
+      }
+      if constexpr (TBK >= 0) {
+        best = quad_max(best);   // the query's four lanes: all 32 rows of the tile
+        if constexpr (TBK == 0) {
+          if (q_valid && kq == 0) {
+            a.part_scores[po + it] = best;
+            a.part_rows[po + it] = t * TR;
+          }
+        } else {
+          if ((it & 3) == kq) { px = best; pr = t * TR; }
+          if ((it & 3) == 3) {
+            insert(px, pr);
+            px = kNegInf;
+            pr = -1;
+          }
+        }
       }
     }
     park_tile(cur ^ 1);
@@ -230,44 +276,106 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     }
     __syncthreads();
     cur ^= 1;
+    ++it;
   }
   if (wave_active) {
-    const size_t o = ((size_t)(q_valid ? qi : 0) * nwg + CRS_STREAM) * a.kp;  // [nq, nwg, kp]
-    flush_lists<L>(sbuf, ibuf, lane, cnt, tau, a.k, a.kp, a.part_scores + o, a.part_rows + o, q_valid);
+    if constexpr (TBK < 0) {
+      flush_lists<L>(sbuf, ibuf, lane, cnt, tau, a.k, a.kp, a.part_scores + po, a.part_rows + po, q_valid);
+    } else if constexpr (TBK == 0) {
+      if (q_valid) {   // slots of tiles this (shorter) stream does not have
+        for (int p = it + kq; p < a.kp; p += 4) {
+          a.part_scores[po + p] = kNegInf;
+          a.part_rows[po + p] = -1;
+        }
+      }
+    } else {
+      insert(px, pr);
+      // fold the four lanes' lists (scan_tb.hip): partner entries arrive out of tile order -> full comparison
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        float os[KK];
+        int orow[KK];
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+          if (round == 0) {
+            const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
+            const auto rr = __builtin_amdgcn_permlane16_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
+            os[j] = __uint_as_float((kq & 1) ? rs[0] : rs[1]);
+            orow[j] = (int)((kq & 1) ? rr[0] : rr[1]);
+          } else {
+            const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
+            const auto rr = __builtin_amdgcn_permlane32_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
+            os[j] = __uint_as_float((kq & 2) ? rs[0] : rs[1]);
+            orow[j] = (int)((kq & 2) ? rr[0] : rr[1]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < KK; ++e) {
+          float x = os[e];
+          int xr = orow[e];
+#pragma unroll
+          for (int j = 0; j < KK; ++j) {
+            const bool c = xr >= 0 && (x > ts[j] || (x == ts[j] && (xr < tr[j] || tr[j] < 0)));
+            const float s_old = ts[j];
+            const int r_old = tr[j];
+            ts[j] = c ? x : s_old;
+            tr[j] = c ? xr : r_old;
+            x = c ? s_old : x;
+            xr = c ? r_old : xr;
+          }
+        }
+      }
+      if (q_valid && kq == 0) {
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+          a.part_scores[po + j] = ts[j];
+          a.part_rows[po + j] = tr[j];
+        }
+      }
+    }
   }
 }
 
-template <int D, int TR, int L>
-int launch_i8(const ScanArgs& a, int nwg, hipStream_t stream) {
+template <int D, int TR, int L, int TBK>
+int launch_i8(const ScanArgs& a, hipStream_t stream) {
   using C = CfgI8<D, TR, L>;
+  constexpr int lds = TBK < 0 ? C::kLds : 2 * C::kTileBytes;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<D, TR, L>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<D, TR, L, TBK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   dim3 grid(a.nqb * a.nwg);           // 1-D; (query block, tile stream) from scan_common.h's grid mapping
-  hipLaunchKernelGGL((scan_i8_kernel<D, TR, L>), grid, dim3(kThreads), C::kLds, stream, a);
+  hipLaunchKernelGGL((scan_i8_kernel<D, TR, L, TBK>), grid, dim3(kThreads), lds, stream, a);
   return (int)hipGetLastError();
 }
 
+// slots: -1 classic, 0 dump, 4 / 10 / 16 chain
 template <int D>
-int launch_i8_d(const ScanArgs& a, int nwg, hipStream_t stream) {
-  if (a.k <= 16) return launch_i8<D, 32, 16>(a, nwg, stream);
-  return launch_i8<D, 32, 32>(a, nwg, stream);
+int launch_i8_d(const ScanArgs& a, int slots, hipStream_t stream) {
+  switch (slots) {
+    case 0: return launch_i8<D, 32, 16, 0>(a, stream);
+    case 4: return launch_i8<D, 32, 16, 4>(a, stream);
+    case 10: return launch_i8<D, 32, 16, 10>(a, stream);
+    case 16: return launch_i8<D, 32, 16, 16>(a, stream);
+    default: break;
+  }
+  if (a.k <= 16) return launch_i8<D, 32, 16, -1>(a, stream);
+  return launch_i8<D, 32, 32, -1>(a, stream);
 }
 
 }  // namespace
 
 int scan_i8_tile_rows() { return 32; }
 
-int scan_launch_i8(const ScanArgs& a, int pdim, int nwg, hipStream_t stream) {
+int scan_launch_i8(const ScanArgs& a, int pdim, int slots, hipStream_t stream) {
   switch (pdim) {
-    case 256: return launch_i8_d<256>(a, nwg, stream);
-    case 512: return launch_i8_d<512>(a, nwg, stream);
-    case 768: return launch_i8_d<768>(a, nwg, stream);
-    case 1024: return launch_i8_d<1024>(a, nwg, stream);
+    case 256: return launch_i8_d<256>(a, slots, stream);
+    case 512: return launch_i8_d<512>(a, slots, stream);
+    case 768: return launch_i8_d<768>(a, slots, stream);
+    case 1024: return launch_i8_d<1024>(a, slots, stream);
     default: return -1;
   }
 }

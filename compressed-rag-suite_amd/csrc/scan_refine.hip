@@ -96,7 +96,113 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
   }
 }
 
+// ---- int8 slabs (scan_i8.hip, tile-best modes).  The scan's score is exact integer arithmetic up to the final
+// scaling: q16 = rint(q / sq), sq = max|q| / 32512, q16 = 256 hi + lo, score = (256 S_hi + S_lo) * sq * s_row
+// with S_x = sum_k row[k] x[k] in int32.  This kernel forms the same integers with plain VALU dot products (one
+// wave per row, D/64 bytes per lane) and applies the same float operations in the same order, so a re-scored
+// row carries bit for bit the score the scan gave it.
+template <int D>
+__global__ __launch_bounds__(kRefThreads) void refine_i8_kernel(const _Float16* __restrict__ q16, const signed char* __restrict__ slab,
+                                                               const float* __restrict__ scales, int n_rows,
+                                                               const float* __restrict__ win_s, const int64_t* __restrict__ win,
+                                                               int k, int tile_rows, int64_t id_base,
+                                                               float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  constexpr int BPL = D / 64;                  // bytes of a row per lane (4, 8, 12 or 16)
+  __shared__ float cs[1024];
+  __shared__ int ci[1024];
+  __shared__ int cnt;
+  __shared__ float red[16];
+  __shared__ short qhi[D], qlo[D];
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) cnt = 0;
+  for (int r = tid; r < k; r += kRefThreads) { out_s[(size_t)q * k + r] = kNegInfR; out_i[(size_t)q * k + r] = -1; }
+  // query scale: max |q| over the row (a max is order-independent, so this equals the scan's value)
+  const _Float16* qrow = q16 + (size_t)q * D;
+  float amax = 0.f;
+  for (int c = tid; c < D; c += kRefThreads) amax = fmaxf(amax, fabsf((float)qrow[c]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if (lane == 0) red[wave] = amax;
+  __syncthreads();
+  amax = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) amax = fmaxf(amax, red[w]);
+  const float qscale = amax > 0.f ? amax / 32512.0f : 1.0f;
+  for (int c = tid; c < D; c += kRefThreads) {
+    const int v = (int)rintf((float)qrow[c] / qscale);
+    const int lo = ((v + 128) & 255) - 128;
+    qlo[c] = (short)lo;
+    qhi[c] = (short)((v - lo) >> 8);
+  }
+  const float t1 = win_s[(size_t)q * k + k - 1];
+  const float tau = (win[(size_t)q * k + k - 1] >= 0) ? t1 : kNegInfR;   // identical arithmetic: no margin needed
+  __syncthreads();
+
+  int myhi[BPL], mylo[BPL];                    // this lane's columns lane * BPL .. + BPL - 1, the same for every row
+#pragma unroll
+  for (int j = 0; j < BPL; ++j) { myhi[j] = qhi[lane * BPL + j]; mylo[j] = qlo[lane * BPL + j]; }
+  const int nrows = k * tile_rows;             // <= 16 * 32
+  for (int u = wave; u < nrows; u += kRefThreads / 64) {
+    const int64_t w = win[(size_t)q * k + u / tile_rows];
+    if (w < 0) continue;                        // wave-uniform
+    const int row = (int)w + (u % tile_rows);
+    if (row >= n_rows) continue;
+    const signed char* src = slab + (size_t)row * D + lane * BPL;
+    int shi = 0, slo = 0;
+#pragma unroll
+    for (int wd = 0; wd < BPL / 4; ++wd) {
+      const int bits = *reinterpret_cast<const int*>(src + wd * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = (bits << (24 - 8 * e)) >> 24;     // sign-extended byte e
+        shi += x * myhi[wd * 4 + e];
+        slo += x * mylo[wd * 4 + e];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { shi += __shfl_xor(shi, o); slo += __shfl_xor(slo, o); }
+    if (lane == 0) {
+      const float sc = ((float)shi * 256.0f + (float)slo) * qscale * scales[row];
+      if (sc >= tau) {
+        const int p = atomicAdd(&cnt, 1);
+        cs[p] = sc;
+        ci[p] = row;
+      }
+    }
+  }
+  __syncthreads();
+  const int m = cnt;
+  for (int c = tid; c < m; c += kRefThreads) {
+    const float s = cs[c];
+    const int id = ci[c];
+    int rank = 0;
+    for (int o = 0; o < m; ++o) {
+      const float so = cs[o];
+      const int io = ci[o];
+      rank += (so > s || (so == s && io < id)) ? 1 : 0;
+    }
+    if (rank < k) { out_s[(size_t)q * k + rank] = s; out_i[(size_t)q * k + rank] = (int64_t)id + id_base; }
+  }
+}
+
 }  // namespace
+
+int refine_i8_launch(const _Float16* q16, int nq, int pdim, const void* slab, const float* scales, int n_rows, const float* win_s,
+                     const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream) {
+  if (k > 16 || tile_rows != 32) return -1;
+#define CRS_REFINE8(DD) hipLaunchKernelGGL((refine_i8_kernel<DD>), dim3(nq), dim3(kRefThreads), 0, stream, q16, \
+                                          reinterpret_cast<const signed char*>(slab), scales, n_rows, win_s, win, k, tile_rows, id_base, out_s, out_i)
+  switch (pdim) {
+    case 256: CRS_REFINE8(256); break;
+    case 512: CRS_REFINE8(512); break;
+    case 768: CRS_REFINE8(768); break;
+    case 1024: CRS_REFINE8(1024); break;
+    default: return -1;
+  }
+#undef CRS_REFINE8
+  return (int)hipGetLastError();
+}
 
 int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, int n_rows, const float* win_s,
                   const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream) {

@@ -87,3 +87,32 @@ def test_store_int8_end_to_end(cuda):
         exp = np.lexsort((np.arange(1200), -full))[:5]
         assert got["ids"][0][0] == f"chunk_{exp[0]}"
         assert len(set(got["ids"][0]) & {f"chunk_{e}" for e in exp}) >= 4   # device-side quantisation may differ by 1 LSB
+
+
+@pytest.mark.parametrize("n,d,nq,k", [
+    (400_000, 768, 64, 10),    # chain mode (long streams), C5's row width
+    (300_000, 256, 16, 4),     # chain, 4 slots
+    (60_000, 768, 130, 16),    # several query blocks, 16 slots
+    (20_000, 512, 64, 10),     # dump mode
+])
+def test_i8_tile_best_modes(cuda, n, d, nq, k):
+    """scan_i8.hip's tile-best modes + refine_i8_kernel at sizes that select each of them."""
+    q, c8, sc = _case(n, d, nq, seed=(n + d) % 3)
+    gs, gi = _run(cuda, q, c8, sc, k)
+    rs, ri = scan_ref.cosine_topk_ref(scan_ref.dequantized_queries(q), c8, k, scales=sc, accumulate=np.float64)
+    assert np.abs(gs - rs).max() < 2e-5
+    mism = gi != ri
+    assert (np.abs(gs - rs)[mism] < 4e-6).all()
+    assert np.mean([scan_ref.recall_at_k(gi[r], ri[r]) for r in range(nq)]) > 0.995
+
+
+def test_i8_chain_mode_ties(cuda):
+    q, c8, sc = _case(400_000, 768, 4, seed=1)
+    full0 = (c8.astype(np.float32) @ scan_ref.dequantized_queries(q)[0].astype(np.float32)) * sc
+    best = int(full0.argmax())
+    planted = sorted({best, 5, 40, 70_001, 250_000, 399_998})
+    for pos in planted:
+        c8[pos] = c8[best]; sc[pos] = sc[best]
+    gs, gi = _run(cuda, q, c8, sc, 10)
+    assert list(gi[0][:len(planted)]) == planted
+    assert (gs[0][:len(planted)] == gs[0][0]).all()
