@@ -28,6 +28,10 @@ import os
 import sys
 import time
 
+# kernel arguments in device memory: ~15 % off the latency of an eagerly launched small kernel on this stack
+# (one 16-token query through the encoder: 232 vs 280 us); must be set before the HIP runtime starts
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "compressed-rag-suite_amd"))
