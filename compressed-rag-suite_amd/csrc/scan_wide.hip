@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
         WP_LAP(3);
       }
     }
-    WP_LAP(4);   // filter + append
+    WP_LAP(4);   // selection (waves 0..3)
     park_tile(sx, tile_buf + (cur ^ 1) * C::kTileBytes);
     WP_LAP(6);   // wait for the next tile + LDS store
     __syncthreads();

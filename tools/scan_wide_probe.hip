@@ -54,8 +54,9 @@ int main(int argc, char** argv) {
   hipMemcpy(hs.data(), st, nst * 8, hipMemcpyDeviceToHost);
   printf("rows %d dim %d nq %d k %d | waves/wg %d nqb %d streams %d tiles/stream %.1f | kernel %.1f us (with stamps)\n", rows, dim, nq, k, nw, nqb, nwg,
          (double)n_tiles / nwg, ms * 1e3);
-  const char* names[12] = {"prologue", "tile-load issue", "sync compaction", "MFMA sweep", "filter+append", "on-demand compaction",
-                           "wait next tile + LDS store", "barrier", "#sync compactions", "#on-demand compactions", "final flush", "TOTAL"};
+  // slots 2 / 4: the selection of waves 4..7 (deferred one tile) / of waves 0..3; 5, 8, 9: unused since the tile-best rewrite
+  const char* names[12] = {"prologue", "tile-load issue", "selection (waves 4-7, deferred)", "MFMA sweep", "selection (waves 0-3)", "(unused)",
+                           "wait next tile + LDS store", "barrier", "(unused)", "(unused)", "final flush", "TOTAL"};
   const size_t nwaves = nst / 12;
   for (int i = 0; i < 12; ++i) {
     std::vector<double> v; for (size_t w = 0; w < nwaves; ++w) v.push_back((double)hs[w * 12 + i]);
