@@ -2,8 +2,9 @@
 //
 //   ctx[b, s, h*hd : (h+1)*hd] = softmax(Q K^T / sqrt(hd) + mask) V        (per batch b, head h)
 //
-// Flash-style: one 256-thread workgroup per (64 query rows, head, batch); wave w owns 16 query
-// rows and keeps their Q fragments, running max / sum and the O accumulators in registers.
+// Flash-style, computed transposed (S^T = K Q^T, O^T = V^T P^T: see the kernel): one 256-thread workgroup per
+// (64 query rows, head, batch); wave w owns 16 query rows and keeps their Q fragments, running max / sum and the
+// O^T accumulators in registers.
 // Keys are visited in blocks of 64: K is staged row-major and V TRANSPOSED in LDS so that both
 // MFMA B operands are 8-byte contiguous reads; scores never leave the chip.  S = Q K^T and
 // O += P V run on v_mfma_f32_16x16x16_f16 (head_dim 16 / 32 / 64 are whole multiples of its K);
@@ -29,14 +30,12 @@ template <int HD>
 __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __restrict__ qkv,
                                                             const int* __restrict__ lens,
                                                             _Float16* __restrict__ ctx, int seq, int hidden) {
-  constexpr int KS = HD / 16;          // k-steps of the QK^T contraction
-  constexpr int NT = HD / 16;          // 16-wide output column tiles of O
+  constexpr int KS = HD / 16;          // k-steps of the Q K^T contraction
+  constexpr int NT = HD / 16;          // 16-row tiles of O^T (head-dim index)
   constexpr int KROW = HD + 4;         // padded K row (halves)
   constexpr int VROW = KB + 4;         // padded V^T row (halves)
-  constexpr int PROW = KB + 4;
   __shared__ __attribute__((aligned(16))) _Float16 sK[KB * KROW];
   __shared__ __attribute__((aligned(16))) _Float16 sVt[HD * VROW];
-  __shared__ __attribute__((aligned(16))) _Float16 sP[4 * 16 * PROW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
@@ -47,7 +46,12 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __r
   const _Float16* base = qkv + (size_t)b * seq * row_stride + h * HD;
   const float scale = 1.0f / sqrtf((float)HD);
 
-  // Q fragments: A[row lr][k = 4g + j + 16 ks]
+  // Everything is computed TRANSPOSED: S^T = K Q^T and O^T = V^T P^T.  With the 16x16x16 accumulator layout
+  // (column = lane & 15, rows 4 (lane >> 4) + i) a lane then holds the scores of ONE query (lane & 15) for 16
+  // keys per block, so the softmax row reductions are 15 register ops + two cross-lane steps instead of four
+  // shuffle steps per row, the per-query rescaling is a per-lane scalar, and P^T leaves the accumulators in
+  // exactly the B-operand layout of the second product (4 consecutive keys of one query): no LDS round trip
+  // for P.  Q fragments (B operand of S^T): lane holds Q[query lr][hd 16 ks + 4 g .. + 4].
   f16x4 qf[KS];
   {
     const int qr = q0 + lr;
@@ -57,111 +61,99 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __r
       qf[ks] = (qr < seq) ? *reinterpret_cast<const f16x4*>(base + (size_t)qr * row_stride + ks * 16 + g * 4) : z;
     }
   }
-  f32x4 o[NT];
+  f32x4 o[NT];                          // O^T tile n: rows = head-dim 16 n + 4 g + i, column = query lr
 #pragma unroll
   for (int n = 0; n < NT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[4], l_run[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { m_run[i] = -1e30f; l_run[i] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;   // of this lane's query
 
-  _Float16* myP = sP + wave * 16 * PROW;
   for (int kb = 0; kb < len; kb += KB) {
     __syncthreads();  // previous block's K / V^T fully consumed
-    // ---- stage K (row-major) and V (transposed) for keys kb .. kb+63
+    // ---- stage K (row-major): one 16-byte chunk per thread and pass
     constexpr int CH = HD / 8;  // 16-byte chunks per key row
     for (int id = tid; id < KB * CH; id += kThreads) {
       const int key = id / CH, c = id % CH;
       const int kr = kb + key;
-      f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-      if (kr < seq) {
-        const _Float16* p = base + (size_t)kr * row_stride + c * 8;
-        kv = *reinterpret_cast<const f16x8*>(p + hidden);
-        vv = *reinterpret_cast<const f16x8*>(p + 2 * hidden);
-      }
+      f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (kr < seq) kv = *reinterpret_cast<const f16x8*>(base + (size_t)kr * row_stride + c * 8 + hidden);
       *reinterpret_cast<f16x4*>(&sK[key * KROW + c * 8]) = f16x4{kv[0], kv[1], kv[2], kv[3]};
       *reinterpret_cast<f16x4*>(&sK[key * KROW + c * 8 + 4]) = f16x4{kv[4], kv[5], kv[6], kv[7]};
+    }
+    // ---- stage V transposed: a thread takes 4 consecutive keys x 8 head-dim columns and writes eight
+    // 8-byte pieces (4 keys of one column) instead of 32 two-byte stores
+    for (int id = tid; id < (KB / 4) * CH; id += kThreads) {
+      const int kg = id / CH, c = id % CH;
+      f16x8 vv[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VROW + key] = vv[e];
+      for (int j = 0; j < 4; ++j) {
+        const int kr = kb + kg * 4 + j;
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        vv[j] = (kr < seq) ? *reinterpret_cast<const f16x8*>(base + (size_t)kr * row_stride + c * 8 + 2 * hidden) : z;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        *reinterpret_cast<f16x4*>(&sVt[(c * 8 + e) * VROW + kg * 4]) = f16x4{vv[0][e], vv[1][e], vv[2][e], vv[3][e]};
     }
     __syncthreads();
 
-    // ---- S = Q K^T for 4 column tiles of 16 keys
+    // ---- S^T = K Q^T for 4 tiles of 16 keys: lane holds keys kb + 16 ct + 4 g + i of query lr
     f32x4 s[4];
+    float mx = -1e30f;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       s[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const f16x4 kf = *reinterpret_cast<const f16x4*>(&sK[(ct * 16 + lr) * KROW + ks * 16 + g * 4]);
-        s[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf[ks], kf, s[ct], 0, 0, 0);
+        s[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[ks], s[ct], 0, 0, 0);
       }
-    }
-    // lane holds rows 4g+i, key column kb + ct*16 + lr
-    float mx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mx[i] = -1e30f;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const bool valid = (kb + ct * 16 + lr) < len;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        const bool valid = (kb + ct * 16 + 4 * g + i) < len;
         s[ct][i] = valid ? s[ct][i] * scale : -1e30f;
-        mx[i] = fmaxf(mx[i], s[ct][i]);
+        mx = fmaxf(mx, s[ct][i]);
       }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], off));
-    }
-    float alpha[4], rs[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float mn = fmaxf(m_run[i], mx[i]);
-      alpha[i] = __expf(m_run[i] - mn);
-      m_run[i] = mn;
-      rs[i] = 0.f;
-    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - mn);
+    m_run = mn;
+    float rs = 0.f;
+    f16x4 pf[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float p = __expf(s[ct][i] - m_run[i]);   // masked keys: exp(-1e30 - m) = 0
-        rs[i] += p;
-        myP[(4 * g + i) * PROW + ct * 16 + lr] = (_Float16)p;
+        const float p = __expf(s[ct][i] - mn);   // masked keys: exp(-1e30 - m) = 0
+        rs += p;
+        pf[ct][i] = (_Float16)p;
       }
     }
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    // ---- O^T = O^T alpha + V^T P^T   (A = V^T[hd 16 n + lr][key 16 ct + 4 g + j], B = P^T from the registers)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int n = 0; n < NT; ++n) {
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) rs[i] += __shfl_xor(rs[i], off);
-      l_run[i] = l_run[i] * alpha[i] + rs[i];
-    }
+      for (int i = 0; i < 4; ++i) o[n][i] *= alpha;
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[n][i] *= alpha[i];
-    // ---- O += P V   (A = P[row lr][key 4g+j+16ks], B = V^T[col n*16+lr][key 4g+j+16ks]); wave-local LDS tile
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int ks = 0; ks < KB / 16; ++ks) {
-      const f16x4 pf = *reinterpret_cast<const f16x4*>(&myP[lr * PROW + ks * 16 + g * 4]);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const f16x4 vf = *reinterpret_cast<const f16x4*>(&sVt[(n * 16 + lr) * VROW + ks * 16 + g * 4]);
-        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(pf, vf, o[n], 0, 0, 0);
+      for (int ct = 0; ct < 4; ++ct) {
+        const f16x4 vf = *reinterpret_cast<const f16x4*>(&sVt[(n * 16 + lr) * VROW + ct * 16 + g * 4]);
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf[ct], o[n], 0, 0, 0);
       }
     }
   }
-  // ---- normalise and store: rows 4g+i, columns n*16 + lr
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int qr = q0 + 4 * g + i;
-    if (qr >= seq) continue;
-    const float inv = 1.0f / l_run[i];
+  // ---- normalise and store: this lane's query q0 + lr, head-dim columns 16 n + 4 g .. + 4 (8-byte stores)
+  const int qr = q0 + lr;
+  if (qr < seq) {
+    const float inv = 1.0f / l_run;
     _Float16* dst = ctx + ((size_t)b * seq + qr) * hidden + h * HD;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) dst[n * 16 + lr] = (_Float16)(o[n][i] * inv);
+    for (int n = 0; n < NT; ++n) {
+      const f16x4 v = {(_Float16)(o[n][0] * inv), (_Float16)(o[n][1] * inv), (_Float16)(o[n][2] * inv), (_Float16)(o[n][3] * inv)};
+      *reinterpret_cast<f16x4*>(dst + n * 16 + 4 * g) = v;
+    }
   }
 }
 

@@ -471,7 +471,13 @@ int launch_l(const ScanArgs& a, int nwg, hipStream_t stream) {
     case 3:
       if (a.boot && L == 16 && TR == 32)
         return launch_kernel(&scan_f16_kernel<D, TR, L, true, (L == 16 && TR == 32)>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[4]);
-      return launch_kernel(&scan_f16_kernel<D, TR, L, true, false>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[3]);
+      // 32-slot lists (k > 16) on rows of >= 512 elements run out of registers and spill a few; an inline-asm
+      // load whose destination the compiler then copies or spills before the data has landed would hand
+      // garbage on, so those instantiations keep compiler-visible loads
+      if constexpr (L == 32 && D >= 512)
+        return launch_kernel(&scan_f16_kernel<D, TR, L, false, false>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[0]);
+      else
+        return launch_kernel(&scan_f16_kernel<D, TR, L, true, false>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[3]);
     case 2: return launch_kernel(&scan_f16_ring_kernel<D, TR, L, 2, 2>, 2 * C::kTileBytes + lists, a, nwg, stream, &done[2]);
     default: {
       constexpr int NS = (L == 16) ? 4 : 3;
