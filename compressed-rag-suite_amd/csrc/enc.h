@@ -37,6 +37,11 @@ int ffn_fused_slices(int hidden, int ffn);   // 0: unsupported shape
 int ffn_fused_launch(const _Float16* x16, const _Float16* w_up, const float* b_up, const _Float16* w_down, float* y32,
                      int tokens, int hidden, int ffn, hipStream_t stream);
 
+// enc_rowln.hip, pipelined variant for large token counts (index build), hidden = 384
+bool gemm_rowln2_supported(int hidden, int k);
+int gemm_rowln2_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, const float* g,
+                       const float* b, float eps, int m, int hidden, int k, float* x32, _Float16* x16, hipStream_t stream);
+
 // enc_attn.hip: ctx[T, H] = softmax(QK^T / sqrt(hd) + padding mask) V per (batch, head);
 // qkv is [T, 3H] fp16 (Q | K | V column blocks), lens[b] real tokens per row (right padding).
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,

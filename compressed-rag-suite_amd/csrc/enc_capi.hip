@@ -36,6 +36,12 @@ bool ffn_enabled() {
   return v == 1;
 }
 
+bool bigln_enabled() {   // CRS_ENC_BIGLN=0: tiled GEMM + separate LayerNorm on the index-build side (A/B runs)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRS_ENC_BIGLN"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 bool qa_enabled() {   // CRS_ENC_QKVATTN=0: separate QKV GEMM and attention launches (A/B runs, tests)
   static int v = -1;
   if (v < 0) { const char* e = getenv("CRS_ENC_QKVATTN"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -48,10 +54,10 @@ bool qa_enabled() {   // CRS_ENC_QKVATTN=0: separate QKV GEMM and attention laun
 // LDS-DMA (~150 cycles of issue per 1 KiB wave-instruction): 1.7 us per 57 KB K-chunk, i.e. 10 us for
 // K = 384 and 41 us for K = 1536, where the split-N / split-K panel GEMM spreads the same bytes over 48-96
 // CUs.  CRS_ENC_ROWLN=1 enables it for experiments.
-bool rowln_enabled() {
+int rowln_enabled() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CRS_ENC_ROWLN"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
+  if (v < 0) { const char* e = getenv("CRS_ENC_ROWLN"); v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0; }
+  return v;
 }
 
 struct Layout {
@@ -153,7 +159,12 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
                                seq, H, d->vocab_size, x32, x16, st), "embed_ln");
   const bool panel_h = use_panel(T, H), panel_f = use_panel(T, F);
   // query-batch regime: projection + bias + residual + LayerNorm as one kernel (enc_rowln.hip)
-  const bool fuse_ln = T <= kPanelMaxTokens && rowln_enabled();
+  // CRS_ENC_ROWLN: 1 = small token counts only (measured slower there), 2 = large token counts only, 3 = both
+  const int rowln_mode = rowln_enabled();
+  const bool fuse_ln = (T <= kPanelMaxTokens) ? (rowln_mode & 1) : (rowln_mode & 2);
+  // index-build side (large token counts), hidden = 384: projection + bias + residual + LayerNorm in one pipelined kernel
+  const bool big_ln = T > kPanelMaxTokens && bigln_enabled();
+  const bool big_ln_h = big_ln && crs::gemm_rowln2_supported(H, H), big_ln_f = big_ln && crs::gemm_rowln2_supported(H, F);
   const bool rowln_h = fuse_ln && crs::gemm_rowln_supported(H, H), rowln_f = fuse_ln && crs::gemm_rowln_supported(H, F);
   const bool single_h = panel_h && crs::gemm_panel_chunk(H) == H;   // K = H fits one chunk: fused fp16 epilogues
   // short sequences in the launch-bound regime: QKV projection + attention as one kernel (enc_qkvattn.hip)
@@ -168,7 +179,9 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, nullptr, qkv, T, 3 * H, H, 0, st), "qkv gemm");
     CRS_TRY(crs::attention_launch(qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "attention");
     }
-    if (rowln_h) {
+    if (big_ln_h) {
+      CRS_TRY(crs::gemm_rowln2_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out projection + layernorm 1");
+    } else if (rowln_h) {
       CRS_TRY(crs::gemm_rowln_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out gemm + layernorm 1");
     } else if (panel_h) {
       CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, st), "out gemm");
@@ -184,7 +197,9 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
     }
     if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_up, L.b_up, ffn, T, F, H, 1, st), "ffn up gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");
-    if (rowln_f) {
+    if (big_ln_f) {
+      CRS_TRY(crs::gemm_rowln2_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down projection + layernorm 2");
+    } else if (rowln_f) {
       CRS_TRY(crs::gemm_rowln_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down gemm + layernorm 2");
     } else if (panel_f) {
       CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, st), "ffn down gemm");

@@ -204,6 +204,169 @@ int launch_rowln(const _Float16* a, const _Float16* w, const float* bias, const 
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// LARGE token counts (index build), H = 384: the same fusion with a pipeline that keeps the CU's DMA port busy.
+// The kernel above pays issue -> round trip -> barrier -> MFMA serially per chunk (1.7 us per 57 KB); with
+// thousands of rows there is no shortage of workgroups, so here a workgroup owns 128 full rows and walks K in
+// chunks of 32 through a FOUR-stage LDS ring, three chunks in flight:
+//   * a stage = A chunk [128, 32] + W chunk [384, 32] = 512 rows of 64 bytes = 32 KB = exactly 32 LDS-DMA
+//     instructions, four per wave -- uniform, so a counted s_waitcnt vmcnt(8) means "chunk ch has landed, the
+//     next two may still be in flight"; 16-byte pieces XOR-swizzled by (row >> 2) & 3 on the source side
+//     (64-byte rows: rows 4 apart share banks);
+//   * per chunk and wave 12 MFMAs (one 32-row block x six 32-column blocks x two k-steps, 7 fragment reads per
+//     6 MFMAs) with the next stage's four DMA instructions issued between them;
+//   * the 128 x 384 fp32 result leaves through the ring's LDS as two 64-row tiles, each normalised row-wise
+//     exactly as in layernorm2_kernel.
+// Replaces gemm_f16_kernel<2> + layernorm2_kernel on the index-build side (65 536 tokens of MiniLM: out-proj
+// 64 us + 47 us, FFN-down 147 us + 47 us before).
+constexpr int kR2Rows = 128, kR2H = 384, kR2Kc = 32, kR2Stages = 4;
+constexpr int kR2StageRows = kR2Rows + kR2H;                  // 512
+constexpr int kR2StageBytes = kR2StageRows * kR2Kc * 2;       // 32 KB
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float16* __restrict__ A,
+                                                                   const _Float16* __restrict__ W,   // [384, K]
+                                                                   const float* __restrict__ bias,
+                                                                   const float* residual,            // may alias x32
+                                                                   const float* __restrict__ g, const float* __restrict__ b,
+                                                                   float eps, int M, int K, float* x32,
+                                                                   _Float16* __restrict__ x16) {
+  constexpr int H = kR2H;
+  extern __shared__ __attribute__((aligned(16))) char r2sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * kR2Rows;
+
+  // ---- DMA geometry: this wave issues instructions wave, wave + 8, wave + 16, wave + 24 of a stage
+  const char* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (i * 8 + wave) * 64 + lane;
+    const int row = p >> 2, cp = p & 3;
+    const int c = cp ^ ((row >> 2) & 3);
+    const _Float16* base = (row < kR2Rows) ? A + (size_t)min(m0 + row, M - 1) * K : W + (size_t)(row - kR2Rows) * K;
+    src[i] = reinterpret_cast<const char*>(base + c * 8);
+  }
+  auto issue_one = [&](int chunk, int i) {
+    char* sb = r2sm + (chunk & (kR2Stages - 1)) * kR2StageBytes + (i * 8 + wave) * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)chunk * (kR2Kc * 2)), (lptr_t)sb, 16, 0, 0);
+  };
+
+  // ---- MFMA geometry: wave -> row block (wave & 3), column blocks 6 (wave >> 2) .. + 5
+  const int fr = lane & 31, fh = lane >> 5;
+  const int rb = wave & 3, cb0 = (wave >> 2) * 6;
+  const int arow = rb * 32 + fr;
+  f32x16 acc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int nchunks = K / kR2Kc;
+#pragma unroll
+  for (int pre = 0; pre < 3; ++pre) {
+    if (pre < nchunks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) issue_one(pre, i);
+    }
+  }
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int ahead = min(2, nchunks - 1 - ch);       // chunks issued after ch that may stay in flight
+    if (ahead == 2) wait_vmcnt<8>(); else if (ahead == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __syncthreads();                                   // chunk ch complete for everyone; stage of chunk ch - 1 is free
+    const bool more = ch + 3 < nchunks;
+    const char* sb = r2sm + (ch & (kR2Stages - 1)) * kR2StageBytes;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * ks + fh;
+      const f16x8 af = *reinterpret_cast<const f16x8*>(sb + arow * 64 + ((c ^ ((arow >> 2) & 3)) << 4));
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int wrow = kR2Rows + (cb0 + j) * 32 + fr;
+        const f16x8 bf = *reinterpret_cast<const f16x8*>(sb + wrow * 64 + ((c ^ ((wrow >> 2) & 3)) << 4));
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[j], 0, 0, 0);
+        if (more && (j == 1 || j == 4)) issue_one(ch + 3, ks * 2 + (j == 4));   // 4 DMA instructions spread over the 12 MFMAs
+      }
+    }
+  }
+  __syncthreads();   // all fragment reads done: the ring becomes the fp32 tile
+
+  // ---- two 64-row halves through LDS, then the row LayerNorm (8-byte form)
+  float* tile = reinterpret_cast<float*>(r2sm);
+  constexpr int ts = H + 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((rb >> 1) == half) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int col = (cb0 + j) * 32 + fr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((rb & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * ts + col] = acc[j][r];
+      }
+    }
+    __syncthreads();
+    for (int row = wave; row < 64; row += 8) {
+      const int gr = m0 + half * 64 + row;
+      if (gr >= M) break;
+      float v[3][2];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = 128 * i + 2 * lane;
+        const float2 t2 = *reinterpret_cast<const float2*>(&tile[row * ts + c]);
+        const float2 bi = bias ? *reinterpret_cast<const float2*>(bias + c) : float2{0.f, 0.f};
+        const float2 re = *reinterpret_cast<const float2*>(residual + (size_t)gr * H + c);
+        v[i][0] = (t2.x + bi.x) + re.x;
+        v[i][1] = (t2.y + bi.y) + re.y;
+        s += v[i][0] + v[i][1];
+      }
+      const float mean = wave_sum_rl(s) / H;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+        q += d0 * d0 + d1 * d1;
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum_rl(q) / H + eps);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = 128 * i + 2 * lane;
+        const float2 gg = *reinterpret_cast<const float2*>(g + c), bb = *reinterpret_cast<const float2*>(b + c);
+        float2 o;
+        o.x = (v[i][0] - mean) * rstd * gg.x + bb.x;
+        o.y = (v[i][1] - mean) * rstd * gg.y + bb.y;
+        *reinterpret_cast<float2*>(x32 + (size_t)gr * H + c) = o;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 hh = {(_Float16)o.x, (_Float16)o.y};
+        *reinterpret_cast<h2*>(x16 + (size_t)gr * H + c) = hh;
+      }
+    }
+    __syncthreads();   // the tile is rewritten by the other half
+  }
+}
+
+}  // namespace
+
+bool gemm_rowln2_supported(int hidden, int k) { return hidden == kR2H && k % kR2Kc == 0 && k >= 3 * kR2Kc; }
+
+int gemm_rowln2_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, const float* g,
+                       const float* b, float eps, int m, int hidden, int k, float* x32, _Float16* x16, hipStream_t stream) {
+  if (!gemm_rowln2_supported(hidden, k)) return -1;
+  constexpr int lds = kR2Stages * kR2StageBytes;   // 128 KB (the 64 x 388 fp32 tile re-uses it)
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rowln2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  hipLaunchKernelGGL(gemm_rowln2_kernel, dim3((m + kR2Rows - 1) / kR2Rows), dim3(kRlThreads), lds, stream, a, w, bias, residual, g, b,
+                     eps, m, k, x32, x16);
+  return (int)hipGetLastError();
+}
+
+namespace {
 }  // namespace
 
 // hidden sizes the fused kernel is instantiated for; K must be a multiple of its chunk (64 / 32)

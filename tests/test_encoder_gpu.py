@@ -163,3 +163,21 @@ def test_fused_qkv_attention_shapes(cuda, batch, seq):
     ref = er.encode_ref(ids, mask, w, cfg)
     assert _cos(got, ref).min() > 1 - 2e-4
     assert np.abs(got - ref).max() < 3e-3
+
+
+def test_index_build_regime_matches_oracle(cuda):
+    """> 4096 tokens per forward: the index-build side of the encoder (streaming QKV / FFN-up GEMMs, the pipelined
+    projection + LayerNorm kernel, transposed attention over several key blocks) against the fp32 oracle; a ragged
+    last row block (4480 tokens = 35 x 128) and ragged sequence lengths included."""
+    cfg = er.MINILM_L6
+    enc, w = _encoder(cfg, 61, cuda)
+    batch, seq = 28, 160
+    ids, mask = er.synth_tokens(cfg, batch, seq, seed=62)
+    rng = np.random.default_rng(63)
+    lens = rng.integers(40, seq + 1, size=batch).astype(np.int32)
+    lens[0] = seq
+    mask = (np.arange(seq)[None, :] < lens[:, None]).astype(np.int32)
+    got = enc.forward(ids, lens).cpu().numpy()
+    ref = er.encode_ref(ids, mask, w, cfg)
+    assert _cos(got, ref).min() > 1 - 2e-4
+    assert np.abs(got - ref).max() < 3e-3
