@@ -29,6 +29,8 @@
 
 #include "enc.h"
 
+#include <stdlib.h>
+
 namespace crs {
 namespace {
 
@@ -218,14 +220,25 @@ int launch_rowln(const _Float16* a, const _Float16* w, const float* bias, const 
 //   * the 128 x 384 fp32 result leaves through the ring's LDS as two 64-row tiles, each normalised row-wise
 //     exactly as in layernorm2_kernel.
 // Replaces gemm_f16_kernel<2> + layernorm2_kernel on the index-build side (65 536 tokens of MiniLM: out-proj
-// 64 us + 47 us, FFN-down 147 us + 47 us before).
-constexpr int kR2Rows = 128, kR2H = 384, kR2Kc = 32, kR2Stages = 4;
+// 64 us + 47 us, FFN-down 147 us + 47 us before).  Measured: the pair of fused launches costs ~245 us per layer
+// (was 305), i.e. ~4 us per 64 KB chunk and CU -- the same ~16-20 GB/s per CU an HBM sweep delivers, although W
+// comes from L2; neither deeper prefetch, nor 128-byte pieces (the default: KC = 64, two stages), nor rotating
+// the K walk per workgroup moved it by more than a few per cent.
+constexpr int kStageInstrPerWave(int kc) { return (128 + 384) * (kc / 8) / 64 / 8; }   // 4 (KC 32) or 8 (KC 64)
+constexpr int kR2Rows = 128, kR2H = 384;
 constexpr int kR2StageRows = kR2Rows + kR2H;                  // 512
-constexpr int kR2StageBytes = kR2StageRows * kR2Kc * 2;       // 32 KB
+// (KC, stages) = (32, 4): 64-byte row pieces, three chunks in flight; (64, 2): 128-byte pieces, one in flight
+template <int KC, int NST>
+struct R2 {
+  static constexpr int kCpr = KC / 8;                          // 16-byte pieces per row: 4 or 8
+  static constexpr int kNi = kStageInstrPerWave(KC);
+  static constexpr int kStageBytes = kR2StageRows * KC * 2;
+};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int KC, int NST>
 __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float16* __restrict__ A,
                                                                    const _Float16* __restrict__ W,   // [384, K]
                                                                    const float* __restrict__ bias,
@@ -234,24 +247,33 @@ __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float
                                                                    float eps, int M, int K, float* x32,
                                                                    _Float16* __restrict__ x16) {
   constexpr int H = kR2H;
+  using C2 = R2<KC, NST>;
+  constexpr int CPR = C2::kCpr, NI = C2::kNi, SH = (CPR == 4) ? 2 : 1;   // swizzle: piece ^ ((row >> SH) & (CPR - 1))
   extern __shared__ __attribute__((aligned(16))) char r2sm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * kR2Rows;
 
   // ---- DMA geometry: this wave issues instructions wave, wave + 8, wave + 16, wave + 24 of a stage
-  const char* src[4];
+  const char* src[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int p = (i * 8 + wave) * 64 + lane;
-    const int row = p >> 2, cp = p & 3;
-    const int c = cp ^ ((row >> 2) & 3);
+    const int row = p / CPR, cp = p % CPR;
+    const int c = cp ^ ((row >> SH) & (CPR - 1));
     const _Float16* base = (row < kR2Rows) ? A + (size_t)min(m0 + row, M - 1) * K : W + (size_t)(row - kR2Rows) * K;
     src[i] = reinterpret_cast<const char*>(base + c * 8);
   }
+  // Workgroups that run side by side would all read the SAME W chunk at the same time (a few hundred L2 lines
+  // hammered by every CU of the XCD); each starts its walk over K at a different chunk instead (the sum over
+  // chunks is the same up to fp32 rounding order).
+  const int nchunks = K / KC;
+  const int rot = (int)(blockIdx.x % (unsigned)nchunks);
   auto issue_one = [&](int chunk, int i) {
-    char* sb = r2sm + (chunk & (kR2Stages - 1)) * kR2StageBytes + (i * 8 + wave) * 1024;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)chunk * (kR2Kc * 2)), (lptr_t)sb, 16, 0, 0);
+    char* sb = r2sm + (chunk % NST) * C2::kStageBytes + (i * 8 + wave) * 1024;
+    int kc = chunk + rot;
+    kc = kc >= nchunks ? kc - nchunks : kc;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)kc * (KC * 2)), (lptr_t)sb, 16, 0, 0);
   };
 
   // ---- MFMA geometry: wave -> row block (wave & 3), column blocks 6 (wave >> 2) .. + 5
@@ -264,30 +286,29 @@ __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const int nchunks = K / kR2Kc;
 #pragma unroll
-  for (int pre = 0; pre < 3; ++pre) {
+  for (int pre = 0; pre < NST - 1; ++pre) {
     if (pre < nchunks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) issue_one(pre, i);
+      for (int i = 0; i < NI; ++i) issue_one(pre, i);
     }
   }
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int ahead = min(2, nchunks - 1 - ch);       // chunks issued after ch that may stay in flight
-    if (ahead == 2) wait_vmcnt<8>(); else if (ahead == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    const int ahead = min(NST - 2, nchunks - 1 - ch);   // chunks issued after ch that may stay in flight
+    if (ahead == 2) wait_vmcnt<2 * NI>(); else if (ahead == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
     __syncthreads();                                   // chunk ch complete for everyone; stage of chunk ch - 1 is free
-    const bool more = ch + 3 < nchunks;
-    const char* sb = r2sm + (ch & (kR2Stages - 1)) * kR2StageBytes;
+    const bool more = ch + NST - 1 < nchunks;
+    const char* sb = r2sm + (ch % NST) * C2::kStageBytes;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KC / 16; ++ks) {
       const int c = 2 * ks + fh;
-      const f16x8 af = *reinterpret_cast<const f16x8*>(sb + arow * 64 + ((c ^ ((arow >> 2) & 3)) << 4));
+      const f16x8 af = *reinterpret_cast<const f16x8*>(sb + arow * (KC * 2) + ((c ^ ((arow >> SH) & (CPR - 1))) << 4));
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const int wrow = kR2Rows + (cb0 + j) * 32 + fr;
-        const f16x8 bf = *reinterpret_cast<const f16x8*>(sb + wrow * 64 + ((c ^ ((wrow >> 2) & 3)) << 4));
+        const f16x8 bf = *reinterpret_cast<const f16x8*>(sb + wrow * (KC * 2) + ((c ^ ((wrow >> SH) & (CPR - 1))) << 4));
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[j], 0, 0, 0);
-        if (more && (j == 1 || j == 4)) issue_one(ch + 3, ks * 2 + (j == 4));   // 4 DMA instructions spread over the 12 MFMAs
+        if (more && (j == 1 || j == 4)) issue_one(ch + NST - 1, ks * 2 + (j == 4));   // NI DMA instructions spread over the MFMAs
       }
     }
   }
@@ -349,20 +370,27 @@ __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float
 
 }  // namespace
 
-bool gemm_rowln2_supported(int hidden, int k) { return hidden == kR2H && k % kR2Kc == 0 && k >= 3 * kR2Kc; }
+bool gemm_rowln2_supported(int hidden, int k) { return hidden == kR2H && k % 64 == 0 && k >= 192; }
 
 int gemm_rowln2_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, const float* g,
                        const float* b, float eps, int m, int hidden, int k, float* x32, _Float16* x16, hipStream_t stream) {
   if (!gemm_rowln2_supported(hidden, k)) return -1;
-  constexpr int lds = kR2Stages * kR2StageBytes;   // 128 KB (the 64 x 388 fp32 tile re-uses it)
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rowln2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  constexpr int lds = 128 * 1024;   // 4 x 32 KB or 2 x 64 KB (the 64 x 388 fp32 tile re-uses it)
+  static int variant = -1;
+  // default: 128-byte row pieces, two stages (3.79 ms per 65 536-token MiniLM forward against 3.86 ms for the
+  // four-stage ring of 64-byte pieces); CRS_ROWLN2_VARIANT=0 selects the latter
+  if (variant < 0) { const char* e = getenv("CRS_ROWLN2_VARIANT"); variant = (e && e[0] == '0') ? 0 : 1; }
+  static bool done[2] = {false, false};
+  auto k0 = &gemm_rowln2_kernel<32, 4>;
+  auto k1 = &gemm_rowln2_kernel<64, 2>;
+  const void* fn = variant ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0);
+  if (!done[variant]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    done = true;
+    done[variant] = true;
   }
-  hipLaunchKernelGGL(gemm_rowln2_kernel, dim3((m + kR2Rows - 1) / kR2Rows), dim3(kRlThreads), lds, stream, a, w, bias, residual, g, b,
-                     eps, m, k, x32, x16);
+  if (variant) hipLaunchKernelGGL(k1, dim3((m + kR2Rows - 1) / kR2Rows), dim3(kRlThreads), lds, stream, a, w, bias, residual, g, b, eps, m, k, x32, x16);
+  else hipLaunchKernelGGL(k0, dim3((m + kR2Rows - 1) / kR2Rows), dim3(kRlThreads), lds, stream, a, w, bias, residual, g, b, eps, m, k, x32, x16);
   return (int)hipGetLastError();
 }
 
