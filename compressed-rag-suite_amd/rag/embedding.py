@@ -25,7 +25,7 @@ import numpy as np
 
 from rag.chunking import Chunk
 from rag import _native as nat
-from rag.tokenizer import HashTokenizer, WordPieceTokenizer, pad_batch
+from rag.tokenizer import HashTokenizer, WordPieceTokenizer, make_wordpiece_tokenizer, pad_batch
 
 logger = logging.getLogger(__name__)
 
@@ -93,7 +93,7 @@ def _load_local_dir(path: str):
                        pooling, min(max_seq, cfg["max_position_embeddings"]))
     raw = load_file(os.path.join(path, "model.safetensors"))
     weights = {(k[5:] if k.startswith("bert.") else k): np.asarray(v, dtype=np.float32) for k, v in raw.items()}
-    tok = WordPieceTokenizer.from_vocab_file(os.path.join(path, "vocab.txt"), lower=lower)
+    tok = make_wordpiece_tokenizer(os.path.join(path, "vocab.txt"), lower=lower)
     return shape, weights, tok
 
 
@@ -150,6 +150,8 @@ class EmbeddingModel:
     # ---- encoding ------------------------------------------------------------------------------
     def tokenize(self, texts: List[str]):
         """-> list of id lists ([CLS] ... [SEP], truncated to max_seq)."""
+        if hasattr(self.tokenizer, "encode_batch"):
+            return self.tokenizer.encode_batch(texts, self.shape.max_seq)
         return [self.tokenizer.encode(t, self.shape.max_seq) for t in texts]
 
     def embed_device(self, texts: Union[str, List[str]]):

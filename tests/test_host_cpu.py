@@ -234,3 +234,28 @@ def test_short_batches_are_padded_to_a_fused_length():
     assert ids.shape == (1, 70)
     ids, lens = pad_batch([[1] * 5], 0)
     assert ids.shape == (1, 5)
+
+
+def test_fast_tokenizer_backend_matches_the_restatement(tmp_path):
+    """rag.tokenizer.FastWordPieceTokenizer (the `tokenizers` library, the reference's own backend) against the pure
+    Python restatement: identical ids on accents, casing, punctuation runs, CJK, control characters, over-long
+    words, unknown pieces and truncation."""
+    pytest.importorskip("tokenizers")
+    from rag.tokenizer import FastWordPieceTokenizer, WordPieceTokenizer, make_wordpiece_tokenizer
+    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "the", "quick", "brown", "fox", "jump", "##s", "##ed", "##ing", "over", "lazy",
+             "dog", ",", ".", "!", "?", "(", ")", "-", "'", "re", "##tri", "##eval", "aug", "##ment", "cafe", "naive", "un",
+             "##believ", "##able", "a", "b", "c", "##a", "##b", "##c", "1", "2", "##3", "中", "文", "$", "%", "e", "##x"]
+    vocab = {w: i for i, w in enumerate(words)}
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(words) + "\n", encoding="utf-8")
+    slow = WordPieceTokenizer(vocab)
+    fast = FastWordPieceTokenizer.from_vocab(vocab)
+    assert isinstance(make_wordpiece_tokenizer(str(vp)), FastWordPieceTokenizer)
+    texts = ["The quick brown fox jumps over the lazy dog.", "Retrieval-augmented... (unbelievable)!?", "Café naïve CAFE",
+             "abc cab 123 12 3", "中文 and 文中", "tab\tnew\nline\x00null​zw", "x" * 120 + " fox", "", "   ", "quick$%fox",
+             "jumping jumped jumps jumpx", "it's 'quoted'", " ".join(["fox"] * 50)]
+    for max_len in (8, 16, 64):
+        got = fast.encode_batch(texts, max_len)
+        for t, g in zip(texts, got):
+            assert g == slow.encode(t, max_len), (t, max_len)
+            assert fast.encode(t, max_len) == g
