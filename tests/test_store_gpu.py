@@ -166,3 +166,21 @@ def test_pipeline_end_to_end_vs_oracle(cuda):
                                                do_rerank=True, diversity_penalty=0.1)} for q in qs]
     res = ir_eval.evaluate_pipeline(pipe, qs, rel, ks=(1, 3))
     assert res["recall@3"] == 1.0 and res["precision@3"] == 1.0 and res["mrr"] == 1.0 and res["num_questions"] == 2
+
+
+@pytest.mark.parametrize("dtype,d", [("fp16", 384), ("fp16", 768), ("int8", 768)])
+def test_large_search_batches_agree_with_single_queries(cuda, dtype, d):
+    """search_batch with more than 64 queries takes the large-batch scan kernels (scan_wide / scan_wide_ks, several
+    query blocks for int8): every row of the batch must equal the one-query search of the same vector, and the
+    reference-semantics store on the host."""
+    store, ref, chunks, emb = _pair(n=3000, d=d, seed=9, index_dtype=dtype)
+    q = scan_ref.synth_queries(emb, 150, seed=10)
+    batch = store.search_batch(q, top_k=5)
+    assert len(batch["ids"]) == 150
+    for i in (0, 1, 63, 64, 65, 127, 128, 149):
+        single = store.search(q[i], top_k=5)
+        assert batch["ids"][i] == single["ids"][0]
+        assert np.allclose(batch["distances"][i], single["distances"][0], atol=1e-6)
+    if dtype == "fp16":
+        same = np.mean([batch["ids"][i] == ref.search(q[i], top_k=5)["ids"][0] for i in range(150)])
+        assert same > 0.97   # fp16 storage vs the fp32 host store: only near-ties may differ
