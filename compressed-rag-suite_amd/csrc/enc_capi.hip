@@ -68,9 +68,14 @@ struct Layout {
 // Small token counts are latency-bound: use the one-shot panel GEMM (+ split-K partials reduced in
 // the LayerNorm); large ones (index build) use the pipelined 128 x 128 kernel.
 constexpr int kPanelMaxTokens = 4096;
+// split-K panels (fp32 partials summed by the LayerNorm) pay off only while the launch is latency-bound: measured at
+// 1024 tokens they beat the tiled kernel (MiniLM step 0.140 vs 0.156 ms; bge equal), at 4096 tokens of bge they lose
+// badly (C3 step 2.79 ms with 2- and 8-way splits against 2.05 ms through the tiled kernel's fused epilogue)
+constexpr int kSplitKMaxTokens = 2048;
 bool use_panel(int tokens, int k) {
   const int kc = crs::gemm_panel_chunk(k);
   if (tokens > kPanelMaxTokens || kc == 0) return false;
+  if (k / kc > 1 && tokens > kSplitKMaxTokens) return false;
   const int ns = k / kc;   // split counts the LayerNorm kernel is instantiated for
   return ns == 1 || ns == 2 || ns == 3 || ns == 4 || ns == 6 || ns == 8;
 }
