@@ -207,6 +207,197 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K = 768 / 1024 (bge-class models): 32 columns x K of W would be 192 / 256 VGPRs, so the contraction is split
+// over the two waves of a SIMD exactly as in scan_wide_ks.hip: 8 waves; waves p and p + 4 own the same 32
+// output columns and one half of K each (K/8 VGPRs of W fragments); wave p + 4 hands its 32 x 32 half-sums
+// over through a double-buffered LDS tile before the tile barrier, wave p adds them to its own (kept across
+// the barrier) and runs the epilogue one tile late -- one wave of a SIMD multiplies while the other stores.
+// fp16 outputs (modes 0 / 1) only; 128 columns per workgroup, one workgroup per CU.
+constexpr int kKsThreads = 512;
+
+template <int K, int MODE>
+__global__ __launch_bounds__(kKsThreads, 2) void gemm_stream_ks_kernel(const _Float16* __restrict__ A,
+                                                                      const _Float16* __restrict__ W,
+                                                                      const float* __restrict__ bias,
+                                                                      _Float16* __restrict__ out, int M, int N, int ncb,
+                                                                      int nstreams) {
+  constexpr int DH = K / 2;
+  constexpr int kCpr = K / 8;
+  constexpr int kTileBytes = TR * K * 2;
+  constexpr int kLoads = kTileBytes / (kKsThreads * 16);
+  constexpr int kKsteps = DH / 16;
+  static_assert(DH % 128 == 0 && kTileBytes % (kKsThreads * 16) == 0, "K/2 must keep the 256-byte swizzle groups whole");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xbuf = reinterpret_cast<float*>(smem + 2 * kTileBytes);                       // [pair][buffer][reg][lane]
+  _Float16* epi = reinterpret_cast<_Float16*>(smem + 2 * kTileBytes + 4 * 2 * 16 * 64 * 4);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3, kh = wave >> 2;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int n_tiles = (M + TR - 1) / TR;
+  const int n_full = M / TR;
+  const int bid = (int)blockIdx.x;
+  const int cblk = (nstreams & 7) ? bid % ncb : (bid >> 3) % ncb;
+  const int strm = (nstreams & 7) ? bid / ncb : ((bid >> 3) / ncb) * 8 + (bid & 7);
+  const int col = cblk * WN + pair * 32 + fr;
+  const bool col_ok = col < N;
+
+  int lds_dst[kLoads];
+#pragma unroll
+  for (int j = 0; j < kLoads; ++j) {
+    const int P = j * kKsThreads + tid;
+    const int r = P / kCpr, c = P % kCpr;
+    lds_dst[j] = (r * kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+  }
+  const char* a_bytes = reinterpret_cast<const char*>(A);
+  const size_t last_chunk = (size_t)M * (K * 2) - 16;
+  u32x4 st[kLoads];
+  auto load_tile = [&](int tile_) {
+    const int tile = __builtin_amdgcn_readfirstlane(tile_);
+    if (tile < n_full) {
+      const char* base = uniform_ptr(a_bytes + (size_t)tile * kTileBytes);
+#pragma unroll
+      for (int j = 0; j < kLoads; ++j) {
+        const unsigned off = (unsigned)(j * kKsThreads + tid) * 16u;
+        u32x4 x;
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
+        st[j] = x;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kLoads; ++j) {
+        size_t off = (size_t)tile * kTileBytes + (size_t)(j * kKsThreads + tid) * 16;
+        off = off > last_chunk ? last_chunk : off;
+        const char* p = a_bytes + off;
+        u32x4 x;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
+        st[j] = x;
+      }
+    }
+  };
+  auto park_tile = [&](char* dst) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) {
+      u32x4 x = st[j];
+      asm volatile("" : "+v"(x));
+      st[j] = x;
+    }
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
+  };
+
+  int t = strm;
+  load_tile(t);
+  f16x8 wf[kKsteps];   // B[k][n]: n = lane & 31, k = kh DH + 16 ks + 8 (lane >> 5) + j
+  {
+    const _Float16* wrow = W + (size_t)(col_ok ? col : 0) * K + kh * DH + fh * 8;
+#pragma unroll
+    for (int ks = 0; ks < kKsteps; ++ks) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      wf[ks] = col_ok ? *reinterpret_cast<const f16x8*>(wrow + ks * 16) : z;
+    }
+#pragma unroll
+    for (int ks = 0; ks < kKsteps; ++ks) {
+      f16x8 x = wf[ks];
+      asm volatile("" : "+v"(x));
+      wf[ks] = x;
+    }
+  }
+  const float bcol = (bias && col_ok) ? bias[col] : 0.f;
+  int a_off[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a_off[m] = fr * (kCpr * 16) + kh * (DH * 2) + ((((m * 2 + fh) ^ fr) & 15) << 4);
+
+  auto sweep = [&](const char* buf) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kKsteps; ++ks) {
+      const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 7] + (ks >> 3) * 256);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf[ks], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+  // epilogue of tile te (the ie-th of the stream): own half-sums + the partner's -> bias / GELU -> LDS tile -> 16-byte stores
+  auto finish = [&](const f32x16& own, int te, int ie) {
+    const float* xb = xbuf + ((pair * 2 + (ie & 1)) * 16) * 64 + lane;
+    _Float16* my = epi + pair * (32 * kEpiStride);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = (own[r] + xb[r * 64]) + bcol;
+      if (MODE == 1) v = gelu_erf_s(v);
+      my[((r & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c0 = cblk * WN + pair * 32;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int lrow = half * 16 + (lane >> 2), lc = (lane & 3) * 8;
+      const f16x8 h = *reinterpret_cast<const f16x8*>(&my[lrow * kEpiStride + lc]);
+      const int row = te * TR + lrow;
+      if (row < M) {
+        _Float16* dst = out + (size_t)row * N + c0 + lc;
+        if (c0 + lc + 7 < N && (N & 7) == 0) {
+          *reinterpret_cast<f16x8*>(dst) = h;
+        } else {
+          for (int e = 0; e < 8 && c0 + lc + e < N; ++e) dst[e] = h[e];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  park_tile(smem);
+  __syncthreads();
+  f32x16 acc_prev;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_prev[r] = 0.f;
+  int cur = 0, it = 0;
+  for (; t < n_tiles; t += nstreams) {
+    load_tile(t + nstreams);
+    const char* buf = smem + cur * kTileBytes;
+    if (kh == 0) {
+      if (it > 0) finish(acc_prev, t - nstreams, it - 1);
+      acc_prev = sweep(buf);
+    } else {
+      const f32x16 acc = sweep(buf);
+      float* xb = xbuf + ((pair * 2 + (it & 1)) * 16) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[r * 64] = acc[r];
+    }
+    park_tile(smem + (cur ^ 1) * kTileBytes);
+    __syncthreads();
+    cur ^= 1;
+    ++it;
+  }
+  if (kh == 0 && it > 0) finish(acc_prev, t - nstreams, it - 1);
+}
+
+template <int K, int MODE>
+int launch_ks(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int cus, hipStream_t stream) {
+  constexpr int lds = 2 * TR * K * 2 + 4 * 2 * 16 * 64 * 4 + 4 * 32 * kEpiStride * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_ks_kernel<K, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int colblocks = (n + WN - 1) / WN;
+  const int n_tiles = (m + TR - 1) / TR;
+  int streams = cus / colblocks;            // one workgroup per CU
+  if (streams < 1) streams = 1;
+  if (streams > n_tiles) streams = n_tiles;
+  if (streams >= 8) streams &= ~7;
+  hipLaunchKernelGGL((gemm_stream_ks_kernel<K, MODE>), dim3(colblocks * streams), dim3(kKsThreads), lds, stream, a, w, bias,
+                     reinterpret_cast<_Float16*>(out), m, n, colblocks, streams);
+  return (int)hipGetLastError();
+}
+
 template <int K, int MODE>
 int launch_k(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n,
              int cus, hipStream_t stream) {
@@ -243,7 +434,7 @@ int launch_mode(const _Float16* a, const _Float16* w, const float* bias, const f
 
 }  // namespace
 
-bool gemm_stream_supported(int k) { return k == 128 || k == 256 || k == 384 || k == 512; }
+bool gemm_stream_supported(int k) { return k == 128 || k == 256 || k == 384 || k == 512 || k == 768; }   // 768: fp16 outputs only
 
 int gemm_stream_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out,
                        int m, int n, int k, int mode, hipStream_t stream) {
@@ -259,6 +450,10 @@ int gemm_stream_launch(const _Float16* a, const _Float16* w, const float* bias, 
     case 256: return launch_mode<256>(a, w, bias, residual, out, m, n, mode, cus, stream);
     case 384: return launch_mode<384>(a, w, bias, residual, out, m, n, mode, cus, stream);
     case 512: return launch_mode<512>(a, w, bias, residual, out, m, n, mode, cus, stream);
+    case 768:
+      if (mode == 0) return launch_ks<768, 0>(a, w, bias, out, m, n, cus, stream);
+      if (mode == 1) return launch_ks<768, 1>(a, w, bias, out, m, n, cus, stream);
+      return -1;
     default: return -1;
   }
 }

@@ -31,7 +31,8 @@ def _cos(a, b):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (200, 384, 384), (1024, 1152, 384), (77, 192, 256), (300, 384, 1536),
-                                   (4100, 1152, 384), (2049, 200, 128), (8192, 1536, 384), (3000, 384, 512), (5000, 96, 256)])
+                                   (4100, 1152, 384), (2049, 200, 128), (8192, 1536, 384), (3000, 384, 512), (5000, 96, 256),
+                                   (4100, 2304, 768), (2049, 520, 768), (600, 3072, 768)])
 def test_gemm_vs_torch_fp32(cuda, mode, m, n, k):
     import torch
     from rag._encoder import gemm_f16

@@ -7,7 +7,7 @@ import torch
 from rag._encoder import gemm_f16
 dev = torch.device("cuda:0")
 shapes = [(4096, 4096, 4096, 0), (65536, 1152, 384, 0), (65536, 1536, 384, 1), (65536, 384, 1536, 2), (65536, 384, 384, 2),
-          (32768, 2304, 768, 0), (32768, 3072, 768, 1), (32768, 768, 3072, 2)]
+          (32768, 2304, 768, 0), (32768, 3072, 768, 1), (32768, 768, 3072, 2), (4096, 2304, 768, 0), (4096, 3072, 768, 1)]
 for m, n, k, mode in shapes:
     a = (torch.randn((m, k), device=dev) * 0.5).half(); w = (torch.randn((n, k), device=dev) * 0.05).half()
     b = torch.randn(n, device=dev); r = torch.randn((m, n), device=dev) if mode == 2 else None
