@@ -161,13 +161,18 @@ int crs_queries_to_f16(const float* q_dev, int nq, int dim, int slab_type, void*
 
 int crs_scan_workspace_bytes(int nq, int dim, int k, int64_t n_rows, size_t* bytes) {
   if (!bytes) return fail(CRS_EINVAL, "null pointer");
-  Plan p;
-  const int rc = make_plan(nq, dim, k, n_rows, CRS_SLAB_F16, &p);
+  Plan p, p8;
+  int rc = make_plan(nq, dim, k, n_rows, CRS_SLAB_F16, &p);
   if (rc) return rc;
-  // sized for the largest grid either slab type can use (resident workgroups), not for n_rows
+  rc = make_plan(nq, dim, k, n_rows, CRS_SLAB_I8, &p8);
+  if (rc) return rc;
+  // the call does not say which slab type will be searched: cover the plans of both, and the largest grid the
+  // threshold kernels can use (resident workgroups), which does not depend on n_rows
   const size_t cap = (size_t)device_cus() * crs::scan_wg_per_cu();
   const size_t classic = ws_bytes(cap * nq * partial_width(k), nq, k);
-  const size_t planned = ws_bytes(p.part_elems, nq, k);
+  size_t planned = ws_bytes(p.part_elems, nq, k);
+  const size_t planned8 = ws_bytes(p8.part_elems, nq, k);
+  if (planned8 > planned) planned = planned8;
   *bytes = classic > planned ? classic : planned;
   return CRS_OK;
 }

@@ -94,6 +94,8 @@ def test_store_int8_end_to_end(cuda):
     (300_000, 256, 16, 4),     # chain, 4 slots
     (60_000, 768, 130, 16),    # several query blocks, 16 slots
     (20_000, 512, 64, 10),     # dump mode
+    (20_000, 256, 64, 1),      # dump mode with more tiles per stream than k: partial lists wider than k
+    (70_000, 768, 40, 3),      #   (found by tools/fuzz_scan.py: the default workspace was sized for the fp16 plan only)
 ])
 def test_i8_tile_best_modes(cuda, n, d, nq, k):
     """scan_i8.hip's tile-best modes + refine_i8_kernel at sizes that select each of them."""

@@ -41,6 +41,7 @@ for ci in range(cases):
         scales = None
         full64 = scan_ref.full_scores_f64(q, c16)
     plan = nat.scan_plan_describe(nq, d, k, n, st)
+    print("   %3d n=%7d d=%4d nq=%3d k=%2d %s %s ..." % (ci, n, d, nq, k, "i8 " if i8 else "f16", plan), flush=True)
     gs, gi = nat.cosine_topk(qd.to(dev), s.to(dev), n, d, k, slab_type=st, scales=scales)
     torch.cuda.synchronize()
     try:
