@@ -73,43 +73,51 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   const int cus = device_cus();
   if (cus <= 0) return fail(CRS_EHIP, "no HIP device available%s");
   p->pdim = crs_row_elems(dim, slab_type);
-  // kernel family: classic threshold/compaction scan (k > 16, int8), or one of the tile-best kernels
-  p->wide_nw = slab_type == CRS_SLAB_F16 ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
-  p->wide_ks = (!p->wide_nw && slab_type == CRS_SLAB_F16 && crs::scan_wide_ks_applies(nq, k, p->pdim)) ? 1 : 0;
-  p->tb_nw = 0;
-  if (!p->wide_nw && !p->wide_ks && slab_type == CRS_SLAB_F16 && k <= 16 && tb_enabled())
-    p->tb_nw = (nq > 64 && crs::scan_tb_has_8_waves(p->pdim)) ? 8 : 4;
-  p->i8_tb = (slab_type == CRS_SLAB_I8 && k <= 16 && tb_enabled()) ? 1 : 0;   // scan_i8.hip's tile-best modes
-  p->tile_rows = p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : p->wide_ks ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
-  p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
-  const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim) : p->wide_ks ? 1
-                         : p->tb_nw ? crs::scan_tb_wg_per_cu(p->pdim, p->tb_nw) : crs::scan_wg_per_cu());
-  // all query blocks of a tile stream must be co-resident: streams = resident slots / query blocks
-  const int qpb = p->wide_nw ? 32 * p->wide_nw : p->wide_ks ? 128 : p->tb_nw ? 16 * p->tb_nw : 64;
-  const int nqb = (nq + qpb - 1) / qpb;
-  p->nqb = nqb;
-  int streams = cap / nqb;
-  if (streams < 1) streams = 1;
-  if (nqb > 1 && streams >= 8) streams &= ~7;   // whole rounds over the 8 XCDs (scan_common.h: grid mapping)
-  p->nwg = p->n_tiles < streams ? p->n_tiles : streams;
-  if (nqb > 1 && p->nwg >= 8) p->nwg &= ~7;
-  p->kp = partial_width(k);
-  p->group_best = 0;
-  p->tb_slots = 0;
-  if (p->wide_nw || p->wide_ks) {          // register chain of the K best tile representatives per lane
-    p->kp = 2 * crs::scan_wide_slots(k);
-    p->group_best = 1;
-  } else if (p->tb_nw || p->i8_tb) {
-    // short streams: every tile's representative goes straight to the partial list ("dump"; merge.hip's
-    // single-pass path takes <= 8192 candidates per query); longer ones keep the K best in registers
-    const int tps = (p->n_tiles + p->nwg - 1) / p->nwg;
-    p->group_best = 1;
-    if ((size_t)tps * p->nwg <= 8192 && tps <= 2 * crs::scan_wide_slots(k)) {
-      p->kp = tps;
-    } else {
-      p->tb_slots = crs::scan_wide_slots(k);
-      p->kp = p->tb_slots;
+  // kernel family: one of the tile-best kernels, or the classic threshold/compaction scan.  The register-chain forms
+  // hold k <= 16; the dump form (short streams) has no such limit and serves k <= 64.  For k > 16 the family is
+  // therefore only known once the stream length is: plan for tile-best first, fall back to classic if it has to chain.
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool allow_tb = attempt == 0 && tb_enabled();
+    p->wide_nw = (allow_tb && slab_type == CRS_SLAB_F16 && k <= 16) ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
+    p->wide_ks = (allow_tb && !p->wide_nw && slab_type == CRS_SLAB_F16 && crs::scan_wide_ks_applies(nq, k, p->pdim)) ? 1 : 0;
+    p->tb_nw = 0;
+    if (allow_tb && !p->wide_nw && !p->wide_ks && slab_type == CRS_SLAB_F16)
+      p->tb_nw = (nq > 64 && k <= 16 && crs::scan_tb_has_8_waves(p->pdim)) ? 8 : 4;
+    p->i8_tb = (allow_tb && slab_type == CRS_SLAB_I8) ? 1 : 0;   // scan_i8.hip's tile-best modes
+    p->tile_rows = p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : p->wide_ks ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
+    p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
+    const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim) : p->wide_ks ? 1
+                           : p->tb_nw ? crs::scan_tb_wg_per_cu(p->pdim, p->tb_nw) : crs::scan_wg_per_cu());
+    // all query blocks of a tile stream must be co-resident: streams = resident slots / query blocks
+    const int qpb = p->wide_nw ? 32 * p->wide_nw : p->wide_ks ? 128 : p->tb_nw ? 16 * p->tb_nw : 64;
+    const int nqb = (nq + qpb - 1) / qpb;
+    p->nqb = nqb;
+    int streams = cap / nqb;
+    if (streams < 1) streams = 1;
+    if (nqb > 1 && streams >= 8) streams &= ~7;   // whole rounds over the 8 XCDs (scan_common.h: grid mapping)
+    p->nwg = p->n_tiles < streams ? p->n_tiles : streams;
+    if (nqb > 1 && p->nwg >= 8) p->nwg &= ~7;
+    p->kp = partial_width(k);
+    p->group_best = 0;
+    p->tb_slots = 0;
+    if (p->wide_nw || p->wide_ks) {          // register chain of the K best tile representatives per lane
+      p->kp = 2 * crs::scan_wide_slots(k);
+      p->group_best = 1;
+    } else if (p->tb_nw || p->i8_tb) {
+      // short streams: every tile's representative goes straight to the partial list ("dump"; merge.hip's
+      // single-pass path takes <= 8192 candidates per query); longer ones keep the K best in registers
+      const int tps = (p->n_tiles + p->nwg - 1) / p->nwg;
+      p->group_best = 1;
+      if ((size_t)tps * p->nwg <= 8192 && tps <= 2 * crs::scan_wide_slots(k)) {
+        p->kp = tps;
+      } else if (k <= 16) {
+        p->tb_slots = crs::scan_wide_slots(k);
+        p->kp = p->tb_slots;
+      } else {
+        continue;                            // k > 16 on a long stream: the threshold kernels
+      }
     }
+    break;
   }
   p->part_elems = (size_t)p->nwg * nq * p->kp;
   return CRS_OK;

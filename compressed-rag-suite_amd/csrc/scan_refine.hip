@@ -32,8 +32,8 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
                                                             const int64_t* __restrict__ win, int k, int tile_rows, int64_t id_base, float* __restrict__ out_s,
                                                             int64_t* __restrict__ out_i) {
   constexpr int kKs = D / 32;
-  __shared__ float cs[1024];   // k * tile_rows <= 16 * 64
-  __shared__ int ci[1024];
+  __shared__ float cs[2048];   // k * tile_rows <= 16 * 64 (chain kernels) or 64 * 32 (dump mode, k <= 64)
+  __shared__ int ci[2048];
   __shared__ int cnt;
   const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
   for (int r = tid; r < k; r += kRefThreads) { out_s[(size_t)q * k + r] = kNegInfR; out_i[(size_t)q * k + r] = -1; }
 
   const int halves = tile_rows / 16;          // 16-row MFMA blocks per tile: 1, 2 or 4
-  const int units = k * halves;               // <= 64
+  const int units = k * halves;               // <= 128
   // Only rows scoring >= the k-th best tile representative can reach the final top-k (that score is
   // attained by k distinct rows already), so the ranking below sees ~k candidates, not k * tile_rows.
   // (a hair below it: scan_wide.hip forms the same dot products with the 32x32x16 MFMA shape, and nothing
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
       for (int ii = 0; ii < 4; ++ii) {
         const int rr = first + 4 * kq + ii;
         if (rr < n_rows && acc[ii] >= tau) {
-          const int p = atomicAdd(&cnt, 1);   // p < units * 16 <= 1024 by construction
+          const int p = atomicAdd(&cnt, 1);   // p < units * 16 <= 2048 by construction
           cs[p] = acc[ii];
           ci[p] = rr;
         }
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kRefThreads) void refine_i8_kernel(const _Float16* 
                                                                int k, int tile_rows, int64_t id_base,
                                                                float* __restrict__ out_s, int64_t* __restrict__ out_i) {
   constexpr int BPL = D / 64;                  // bytes of a row per lane (4, 8, 12 or 16)
-  __shared__ float cs[1024];
-  __shared__ int ci[1024];
+  __shared__ float cs[2048];
+  __shared__ int ci[2048];
   __shared__ int cnt;
   __shared__ float red[16];
   __shared__ short qhi[D], qlo[D];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_i8_kernel(const _Float16* 
   int myhi[BPL], mylo[BPL];                    // this lane's columns lane * BPL .. + BPL - 1, the same for every row
 #pragma unroll
   for (int j = 0; j < BPL; ++j) { myhi[j] = qhi[lane * BPL + j]; mylo[j] = qlo[lane * BPL + j]; }
-  const int nrows = k * tile_rows;             // <= 16 * 32
+  const int nrows = k * tile_rows;             // <= 64 * 32
   for (int u = wave; u < nrows; u += kRefThreads / 64) {
     const int64_t w = win[(size_t)q * k + u / tile_rows];
     if (w < 0) continue;                        // wave-uniform
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_i8_kernel(const _Float16* 
 
 int refine_i8_launch(const _Float16* q16, int nq, int pdim, const void* slab, const float* scales, int n_rows, const float* win_s,
                      const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream) {
-  if (k > 16 || tile_rows != 32) return -1;
+  if (k > 64 || tile_rows != 32) return -1;
 #define CRS_REFINE8(DD) hipLaunchKernelGGL((refine_i8_kernel<DD>), dim3(nq), dim3(kRefThreads), 0, stream, q16, \
                                           reinterpret_cast<const signed char*>(slab), scales, n_rows, win_s, win, k, tile_rows, id_base, out_s, out_i)
   switch (pdim) {
@@ -206,7 +206,7 @@ int refine_i8_launch(const _Float16* q16, int nq, int pdim, const void* slab, co
 
 int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, int n_rows, const float* win_s,
                   const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream) {
-  if (k > 16 || (tile_rows != 16 && tile_rows != 32 && tile_rows != 64)) return -1;
+  if (k > 64 || (tile_rows != 16 && tile_rows != 32 && tile_rows != 64) || k * tile_rows > 2048) return -1;
 #define CRS_REFINE(DD) hipLaunchKernelGGL((refine_kernel<DD>), dim3(nq), dim3(kRefThreads), 0, stream, q16, slab, n_rows, win_s, win, k, tile_rows, \
                                          id_base, out_s, out_i)
   switch (pdim) {

@@ -1,4 +1,4 @@
-// scan_tb.hip -- "tile best" form of the 16x16x32 scan (fp16 slabs, k <= 16): the default for 64-query
+// scan_tb.hip -- "tile best" form of the 16x16x32 scan (fp16 slabs; chain form k <= 16, dump form k <= 64): the default for 64-query
 // batches, and for larger batches of rows wider than 512 elements (scan_wide.hip takes the others).
 //
 // scan.hip filters every score against a running per-query threshold, appends survivors to per-lane
