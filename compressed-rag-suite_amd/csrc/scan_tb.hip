@@ -110,7 +110,14 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
 #endif
   };
 
+#ifdef CRS_TB_CONTIG   /* timing experiment (tools/scan_tb_probe): every stream walks ONE contiguous run of tiles */
+  const int tps_ = (a.n_tiles + nwg - 1) / nwg;
+  const int tstep = 1, tend = min(a.n_tiles, (stream + 1) * tps_);
+  int t = stream * tps_;
+#else
+  const int tstep = nwg, tend = a.n_tiles;
   int t = stream;
+#endif
   load_tile(st0, t);   // before the query fragments are fetched: the two latencies overlap
   const int lr = lane & 15, kq = lane >> 4;
   const int qi = qbase + lr;
@@ -159,14 +166,14 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
     }
   };
 
-  if constexpr (PF == 2) load_tile(st1, t + nwg);   // after the query loads: the counted wait below covers st0 + queries
+  if constexpr (PF == 2) load_tile(st1, t + tstep);   // after the query loads: the counted wait below covers st0 + queries
   park_tile(st0, tile_buf);
   __syncthreads();
 
   int cur = 0, it = 0;
   // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
   auto body = [&](auto& sx, auto& sy) {
-    if constexpr (PF == 2) load_tile(sy, t + 2 * nwg); else load_tile(sx, t + nwg);
+    if constexpr (PF == 2) load_tile(sy, t + 2 * tstep); else load_tile(sx, t + tstep);
 #ifdef CRS_TB_EXPERIMENT   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either) */
     if (false) {
 #else
@@ -209,16 +216,16 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
     __syncthreads();
     cur ^= 1;
     ++it;
-    t += nwg;
+    t += tstep;
   };
   if constexpr (PF == 2) {
-    while (t < a.n_tiles) {
+    while (t < tend) {
       body(st1, st0);
-      if (t >= a.n_tiles) break;
+      if (t >= tend) break;
       body(st0, st1);
     }
   } else {
-    while (t < a.n_tiles) body(st0, st0);
+    while (t < tend) body(st0, st0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail prefetches (clamped re-reads) must not outlive the registers
   if (wave_active) {
