@@ -173,7 +173,14 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   int cur = 0, it = 0;
   // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
   auto body = [&](auto& sx, auto& sy) {
-    if constexpr (PF == 2) load_tile(sy, t + 2 * tstep); else load_tile(sx, t + tstep);
+    // two tiles ahead: half of the waves issue their share before the math, the other half after it, so a
+    // workgroup's 24 KB does not leave as one burst (1-2 % on C4; each wave's counted wait below still means
+    // "everything but my youngest tile has landed")
+    if constexpr (PF == 2) {
+      if (wave < NW / 2) load_tile(sy, t + 2 * tstep);
+    } else {
+      load_tile(sx, t + tstep);
+    }
 #ifdef CRS_TB_EXPERIMENT   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either) */
     if (false) {
 #else
@@ -211,6 +218,9 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
           pr = -1;
         }
       }
+    }
+    if constexpr (PF == 2) {
+      if (wave >= NW / 2) load_tile(sy, t + 2 * tstep);
     }
     park_tile(sx, tile_buf + (cur ^ 1) * C::kTileBytes);
     __syncthreads();
