@@ -190,8 +190,6 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   int tr[KK];
 #pragma unroll
   for (int j = 0; j < KK; ++j) { ts[j] = kNegInf; tr[j] = -1; }
-  float px = kNegInf;
-  int pr = -1;
   int it = 0;
   auto insert = [&](float x, int xr) {
 #pragma unroll
@@ -259,12 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
             a.part_rows[po + it] = t * TR;
           }
         } else {
-          if ((it & 3) == kq) { px = best; pr = t * TR; }
-          if ((it & 3) == 3) {
-            insert(px, pr);
-            px = kNegInf;
-            pr = -1;
-          }
+          insert(best, t * TR);   // all four lanes of the query keep the same list (scan_tb.hip): no fold at the exit
         }
       }
     }
@@ -289,42 +282,6 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
         }
       }
     } else {
-      insert(px, pr);
-      // fold the four lanes' lists (scan_tb.hip): partner entries arrive out of tile order -> full comparison
-#pragma unroll
-      for (int round = 0; round < 2; ++round) {
-        float os[KK];
-        int orow[KK];
-#pragma unroll
-        for (int j = 0; j < KK; ++j) {
-          if (round == 0) {
-            const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
-            const auto rr = __builtin_amdgcn_permlane16_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
-            os[j] = __uint_as_float((kq & 1) ? rs[0] : rs[1]);
-            orow[j] = (int)((kq & 1) ? rr[0] : rr[1]);
-          } else {
-            const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
-            const auto rr = __builtin_amdgcn_permlane32_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
-            os[j] = __uint_as_float((kq & 2) ? rs[0] : rs[1]);
-            orow[j] = (int)((kq & 2) ? rr[0] : rr[1]);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < KK; ++e) {
-          float x = os[e];
-          int xr = orow[e];
-#pragma unroll
-          for (int j = 0; j < KK; ++j) {
-            const bool c = xr >= 0 && (x > ts[j] || (x == ts[j] && (xr < tr[j] || tr[j] < 0)));
-            const float s_old = ts[j];
-            const int r_old = tr[j];
-            ts[j] = c ? x : s_old;
-            tr[j] = c ? xr : r_old;
-            x = c ? s_old : x;
-            xr = c ? r_old : xr;
-          }
-        }
-      }
       if (q_valid && kq == 0) {
 #pragma unroll
         for (int j = 0; j < KK; ++j) {

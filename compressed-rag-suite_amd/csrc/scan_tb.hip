@@ -12,8 +12,10 @@
 //   * K = 0, "dump": streams of at most a few tiles write every representative straight to the
 //     workgroup's partial list (slot = tile number in the stream);
 //   * K > 0, "chain": the representative goes into a register-resident sorted list of the K best so far
-//     (branch-free compare-exchange chain, 5 VALU per slot).  A query's four lanes take turns -- lane
-//     group kq inserts the tiles with (tile number & 3) == kq -- so the chain runs once per FOUR tiles.
+//     (branch-free compare-exchange chain, 5 VALU per slot).  All four lanes of a query insert every tile and
+//     so hold the same list: letting them take turns (a quarter of the chain work) left a fold of the four
+//     lists for the exit -- 200 dependent compare-exchange steps, 37 k cycles during which the workgroup loads
+//     nothing, a tenth of the C4 launch -- whereas the chain inside the loop hides behind the memory waits.
 // No LDS lists, no data-dependent branch, 2 tiles of LDS per workgroup: three workgroups (tiles in
 // flight) per CU where the registers allow.  NW = 4 waves serve 64 queries; NW = 8 serve 128 from one
 // staged copy of the tile (rows wider than 512 elements, where scan_wide.hip's 32-query fragments no
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = CRS_NSTREAMS;
   const int stream = CRS_STREAM;
+  WP_DECL;
   const int qbase = CRS_QBLOCK * (NW * 16) + wave * 16;
   const bool wave_active = qbase < a.nq;
 
@@ -94,8 +97,13 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   };
   // wait until all but the youngest tile's loads have landed (vmcnt counts in issue order), then move
   // this set into LDS
-  auto park_tile = [&](auto& st, char* dst) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF == 2 ? C::kLoads : 0) : "memory");
+  auto park_tile = [&](auto& st, char* dst, bool younger_in_flight) {
+    if (PF == 2 && younger_in_flight) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::kLoads) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    WP_LAP(5);   // wait for the tile's loads
 #pragma unroll
     for (int j = 0; j < C::kLoads; ++j) {
       u32x4 x = st[j];
@@ -151,8 +159,6 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   int tr[KK];
 #pragma unroll
   for (int j = 0; j < KK; ++j) { ts[j] = kNegInf; tr[j] = -1; }
-  float px = kNegInf;   // pending candidate of this lane
-  int pr = -1;
   auto insert = [&](float x, int xr) {
 #pragma unroll
     for (int j = 0; j < KK; ++j) {
@@ -167,8 +173,9 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   };
 
   if constexpr (PF == 2) load_tile(st1, t + tstep);   // after the query loads: the counted wait below covers st0 + queries
-  park_tile(st0, tile_buf);
+  park_tile(st0, tile_buf, true);
   __syncthreads();
+  WP_LAP(0);   // prologue
 
   int cur = 0, it = 0;
   // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
@@ -176,12 +183,15 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
     // two tiles ahead: half of the waves issue their share before the math, the other half after it, so a
     // workgroup's 24 KB does not leave as one burst (1-2 % on C4; each wave's counted wait below still means
     // "everything but my youngest tile has landed")
+    // (no loads past the stream's end: they would only queue behind everybody else's and be waited for at the exit)
+    const bool has1 = t + tstep < tend, has2 = t + 2 * tstep < tend;
     if constexpr (PF == 2) {
-      if (wave < NW / 2) load_tile(sy, t + 2 * tstep);
+      if (has2 && wave < NW / 2) load_tile(sy, t + 2 * tstep);
     } else {
-      load_tile(sx, t + tstep);
+      if (has1) load_tile(sx, t + tstep);
     }
-#ifdef CRS_TB_EXPERIMENT   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either) */
+    WP_LAP(1);   // look-ahead issue (first half of the waves)
+#if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT <= 2   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either, 3: fragment reads without MFMA, 4: MFMA without fragment reads) */
     if (false) {
 #else
     if (wave_active) {
@@ -193,8 +203,15 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < C::kKsteps; ++ks) {
+#if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT == 3
+          const f32x4 af = *reinterpret_cast<const f32x4*>(buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
+          acc[ks & 3] += af[ks & 3];
+#elif defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT == 4
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[(ks + rt) % C::kKsteps], qf[ks], acc, 0, 0, 0);
+#else
           const f16x8 af = *reinterpret_cast<const f16x8*>(buf + a_off[ks & 3] + rt * 16 * (C::kCpr * 16) + (ks >> 2) * 256);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qf[ks], acc, 0, 0, 0);
+#endif
         }
         if (t < n_full) {
           best = fmaxf(best, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
           for (int i = 0; i < 4; ++i) best = (row0 + i < a.n_rows) ? fmaxf(best, acc[i]) : best;
         }
       }
+      WP_LAP(3);   // fragment reads + MFMA
       best = quad_max(best);   // the query's four lanes: all rows of the tile
       if constexpr (K == 0) {
         if (q_valid && kq == 0) {
@@ -211,19 +229,20 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
           out_i[it] = t * TR;
         }
       } else {
-        if ((it & 3) == kq) { px = best; pr = t * TR; }   // lane group kq is responsible for these tiles
-        if ((it & 3) == 3) {
-          insert(px, pr);
-          px = kNegInf;
-          pr = -1;
-        }
+        insert(best, t * TR);   // all four lanes of the query: they hold the same list, so nothing is left to fold at the exit
       }
     }
+    WP_LAP(4);   // selection
     if constexpr (PF == 2) {
-      if (wave >= NW / 2) load_tile(sy, t + 2 * tstep);
+      if (has2 && wave >= NW / 2) load_tile(sy, t + 2 * tstep);
     }
-    park_tile(sx, tile_buf + (cur ^ 1) * C::kTileBytes);
-    __syncthreads();
+    WP_LAP(2);   // look-ahead issue (second half of the waves)
+    if (has1) {
+      park_tile(sx, tile_buf + (cur ^ 1) * C::kTileBytes, has2);
+      WP_LAP(6);   // LDS store
+      __syncthreads();
+      WP_LAP(7);   // barrier
+    }
     cur ^= 1;
     ++it;
     t += tstep;
@@ -237,7 +256,8 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   } else {
     while (t < tend) body(st0, st0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail prefetches (clamped re-reads) must not outlive the registers
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a one-tile stream's prologue look-ahead must not outlive the registers
+  WP_LAP(8);
   if (wave_active) {
     if constexpr (K == 0) {
       if (q_valid) {   // slots of tiles this (shorter) stream does not have
@@ -247,45 +267,6 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
         }
       }
     } else {
-      insert(px, pr);   // tiles of an unfinished round of four (a no-op for lanes with nothing pending)
-      // Fold the four lanes' lists into the query's K best: each lane inserts its partner's K entries
-      // (lane ^ 16, then lane ^ 32); afterwards all four hold the same list and one of them writes it.
-      // Entries of different lanes arrive out of tile order, so here ties are decided by the full
-      // (score desc, first row asc) comparison.
-#pragma unroll
-      for (int round = 0; round < 2; ++round) {
-        float os[KK];
-        int orow[KK];
-#pragma unroll
-        for (int j = 0; j < KK; ++j) {
-          if (round == 0) {
-            const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
-            const auto rr = __builtin_amdgcn_permlane16_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
-            os[j] = __uint_as_float((kq & 1) ? rs[0] : rs[1]);     // [0]: even 16-lane rows, [1]: odd rows
-            orow[j] = (int)((kq & 1) ? rr[0] : rr[1]);
-          } else {
-            const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ts[j]), __float_as_uint(ts[j]), false, false);
-            const auto rr = __builtin_amdgcn_permlane32_swap((unsigned)tr[j], (unsigned)tr[j], false, false);
-            os[j] = __uint_as_float((kq & 2) ? rs[0] : rs[1]);     // [0]: lanes 0..31, [1]: lanes 32..63
-            orow[j] = (int)((kq & 2) ? rr[0] : rr[1]);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < KK; ++e) {
-          float x = os[e];
-          int xr = orow[e];
-#pragma unroll
-          for (int j = 0; j < KK; ++j) {
-            const bool c = xr >= 0 && (x > ts[j] || (x == ts[j] && (xr < tr[j] || tr[j] < 0)));
-            const float s_old = ts[j];
-            const int r_old = tr[j];
-            ts[j] = c ? x : s_old;
-            tr[j] = c ? xr : r_old;
-            x = c ? s_old : x;
-            xr = c ? r_old : xr;
-          }
-        }
-      }
       if (q_valid && kq == 0) {    // kp = K
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -295,6 +276,8 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
       }
     }
   }
+  WP_LAP(10);   // final fold + write
+  WP_STORE(NW);
 }
 
 template <int D, int TR, int NW, int K>

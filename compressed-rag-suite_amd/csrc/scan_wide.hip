@@ -39,18 +39,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// tools/scan_wide_probe.hip: per-wave cycle accumulators (diagnostic build only)
-#ifdef CRS_STAMPS
-#define WP_DECL unsigned long long wp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long wp_t_ = __builtin_amdgcn_s_memtime(); const unsigned long long wp_t0_ = wp_t_
-#define WP_LAP(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); wp_[slot] += n_ - wp_t_; wp_t_ = n_; } while (0)
-#define WP_COUNT(slot) do { ++wp_[slot]; } while (0)
-#define WP_STORE(nw_) do { if (a.stamps && lane == 0) { wp_[11] = __builtin_amdgcn_s_memtime() - wp_t0_; for (int i_ = 0; i_ < 12; ++i_) a.stamps[((size_t)blockIdx.x * (nw_) + wave) * 12 + i_] = wp_[i_]; } } while (0)
-#else
-#define WP_DECL do {} while (0)
-#define WP_LAP(slot) do {} while (0)
-#define WP_COUNT(slot) do {} while (0)
-#define WP_STORE(nw_) do {} while (0)
-#endif
+
 
 
 // rows per tile: 32 * RB (RB 32x32 MFMA row blocks).  The 8-wave kernel takes 64-row tiles where the registers

@@ -35,6 +35,30 @@ int main(int argc, char** argv) {
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / it;
+#ifdef CRS_STAMPS
+  {   // per-wave cycle accumulators (s_memtime ticks: 100 MHz)
+    const size_t nst = (size_t)nwg * 4 * 12;
+    unsigned long long* st; hipMalloc(&st, nst * 8); hipMemset(st, 0, nst * 8);
+    a.stamps = st;
+    crs::scan_launch_tb(a, dim, 4, slots, 0);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> hs(nst);
+    hipMemcpy(hs.data(), st, nst * 8, hipMemcpyDeviceToHost);
+    const char* names[12] = {"prologue", "issue (waves 0-1)", "issue (waves 2-3)", "fragment reads + MFMA", "selection", "wait for loads",
+                             "LDS store", "barrier", "exit wait", "", "final fold", "TOTAL"};
+    for (int half = 0; half < 2; ++half) {
+      printf(" waves %d-%d\n", half * 2, half * 2 + 1);
+      for (int i = 0; i < 12; ++i) {
+        if (!names[i][0]) continue;
+        std::vector<double> v;
+        for (size_t w = 0; w < nst / 12; ++w) if ((int)(w & 3) / 2 == half) v.push_back((double)hs[w * 12 + i]);
+        std::sort(v.begin(), v.end());
+        double sum = 0; for (double x : v) sum += x;
+        printf("  %-24s mean %9.0f  median %9.0f  max %9.0f\n", names[i], sum / v.size(), v[v.size() / 2], v.back());
+      }
+    }
+  }
+#endif
   printf("rows %d dim %d nq %d  streams %d (%d/CU) tiles/stream %.1f slots %d : %.1f us  %.0f GB/s\n", rows, dim, nq, nwg, wgpc,
          (double)n_tiles / nwg, slots, us, (double)rows * dim * 2 / us / 1e3);
   return 0;
