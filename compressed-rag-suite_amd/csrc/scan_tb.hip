@@ -16,8 +16,7 @@
 //     so hold the same list: letting them take turns (a quarter of the chain work) left a fold of the four
 //     lists for the exit -- 200 dependent compare-exchange steps, 37 k cycles during which the workgroup loads
 //     nothing, a tenth of the C4 launch -- whereas the chain inside the loop hides behind the memory waits.
-// No LDS lists, no data-dependent branch, 2 tiles of LDS per workgroup: three workgroups (tiles in
-// flight) per CU where the registers allow.  NW = 4 waves serve 64 queries; NW = 8 serve 128 from one
+// No LDS lists, no data-dependent branch, 2 tiles of LDS per workgroup, two workgroups per CU (TbCfg).  NW = 4 waves serve 64 queries; NW = 8 serve 128 from one
 // staged copy of the tile (rows wider than 512 elements, where scan_wide.hip's 32-query fragments no
 // longer fit the register file).
 
@@ -38,9 +37,10 @@ struct TbCfg {
   static constexpr int kRt = TR / 16;
   static constexpr int kLds = 2 * kTileBytes;
   // resident workgroups per CU the kernel is built for (LDS and a 512 / waves-per-SIMD register budget)
-  static constexpr int kWgpc = NW == 8 ? (D <= 384 ? 2 : 1) : (D <= 384 ? 3 : 2);
-  // tiles in flight per workgroup: a second register staging set where the register budget has room
-  static constexpr int kPf = (NW == 4 && D <= 384) ? 2 : 1;
+  // one look-ahead tile per workgroup and two workgroups per CU: 48 KB in flight per CU is where a plain sweep of
+  // HBM peaks as well; a second look-ahead tile or a third workgroup only lengthen the memory queues (C4:
+  // 5.6-5.8 TB/s against 6.05).  128-element rows (8 KB tiles) take three.
+  static constexpr int kWgpc = NW == 8 ? (D <= 384 ? 2 : 1) : (D <= 128 ? 3 : 2);
   static_assert(D % 128 == 0 && TR % 16 == 0, "row length: multiple of 128 elements; tile rows: multiple of 16");
   static_assert(kTileBytes % (kT * 16) == 0, "tile must split into whole 16-byte loads");
 };
@@ -70,9 +70,8 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
   const int n_full = a.n_rows / TR;
-  constexpr int PF = (C::kPf == 2 && K <= 10) ? 2 : 1;   // K = 16: the chain leaves no room for the second set
-  u32x4 st0[C::kLoads], st1[PF == 2 ? C::kLoads : 1];
-  auto load_tile = [&](auto& st, int tile_) {
+  u32x4 st[C::kLoads];   // the look-ahead tile on its way to LDS
+  auto load_tile = [&](int tile_) {
     const int tile = __builtin_amdgcn_readfirstlane(tile_);
     if (tile < n_full) {
       const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
@@ -95,14 +94,9 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
       }
     }
   };
-  // wait until all but the youngest tile's loads have landed (vmcnt counts in issue order), then move
-  // this set into LDS
-  auto park_tile = [&](auto& st, char* dst, bool younger_in_flight) {
-    if (PF == 2 && younger_in_flight) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::kLoads) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  // wait for the look-ahead tile and move it into LDS
+  auto park_tile = [&](char* dst) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WP_LAP(5);   // wait for the tile's loads
 #pragma unroll
     for (int j = 0; j < C::kLoads; ++j) {
@@ -126,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   const int tstep = nwg, tend = a.n_tiles;
   int t = stream;
 #endif
-  load_tile(st0, t);   // before the query fragments are fetched: the two latencies overlap
+  load_tile(t);   // before the query fragments are fetched: the two latencies overlap
   const int lr = lane & 15, kq = lane >> 4;
   const int qi = qbase + lr;
   const bool q_valid = qi < a.nq;
@@ -172,25 +166,17 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
     }
   };
 
-  if constexpr (PF == 2) load_tile(st1, t + tstep);   // after the query loads: the counted wait below covers st0 + queries
-  park_tile(st0, tile_buf, true);
+  park_tile(tile_buf);
   __syncthreads();
   WP_LAP(0);   // prologue
 
   int cur = 0, it = 0;
-  // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
-  auto body = [&](auto& sx, auto& sy) {
-    // two tiles ahead: half of the waves issue their share before the math, the other half after it, so a
-    // workgroup's 24 KB does not leave as one burst (1-2 % on C4; each wave's counted wait below still means
-    // "everything but my youngest tile has landed")
-    // (no loads past the stream's end: they would only queue behind everybody else's and be waited for at the exit)
-    const bool has1 = t + tstep < tend, has2 = t + 2 * tstep < tend;
-    if constexpr (PF == 2) {
-      if (has2 && wave < NW / 2) load_tile(sy, t + 2 * tstep);
-    } else {
-      if (has1) load_tile(sx, t + tstep);
-    }
-    WP_LAP(1);   // look-ahead issue (first half of the waves)
+  // one iteration: tile t sits in LDS buffer `cur`; tile t + nwg is fetched while t is multiplied (no loads past
+  // the stream's end: they would only queue behind everybody else's)
+  while (t < tend) {
+    const bool has1 = t + tstep < tend;
+    if (has1) load_tile(t + tstep);
+    WP_LAP(1);   // look-ahead issue
 #if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT <= 2   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either, 3: fragment reads without MFMA, 4: MFMA without fragment reads) */
     if (false) {
 #else
@@ -233,12 +219,8 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
       }
     }
     WP_LAP(4);   // selection
-    if constexpr (PF == 2) {
-      if (has2 && wave >= NW / 2) load_tile(sy, t + 2 * tstep);
-    }
-    WP_LAP(2);   // look-ahead issue (second half of the waves)
     if (has1) {
-      park_tile(sx, tile_buf + (cur ^ 1) * C::kTileBytes, has2);
+      park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
       WP_LAP(6);   // LDS store
       __syncthreads();
       WP_LAP(7);   // barrier
@@ -246,18 +228,7 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
     cur ^= 1;
     ++it;
     t += tstep;
-  };
-  if constexpr (PF == 2) {
-    while (t < tend) {
-      body(st1, st0);
-      if (t >= tend) break;
-      body(st0, st1);
-    }
-  } else {
-    while (t < tend) body(st0, st0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a one-tile stream's prologue look-ahead must not outlive the registers
-  WP_LAP(8);
   if (wave_active) {
     if constexpr (K == 0) {
       if (q_valid) {   // slots of tiles this (shorter) stream does not have

@@ -44,8 +44,8 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     std::vector<unsigned long long> hs(nst);
     hipMemcpy(hs.data(), st, nst * 8, hipMemcpyDeviceToHost);
-    const char* names[12] = {"prologue", "issue (waves 0-1)", "issue (waves 2-3)", "fragment reads + MFMA", "selection", "wait for loads",
-                             "LDS store", "barrier", "exit wait", "", "final fold", "TOTAL"};
+    const char* names[12] = {"prologue", "look-ahead issue", "", "fragment reads + MFMA", "selection", "wait for loads",
+                             "LDS store", "barrier", "", "", "exit", "TOTAL"};
     for (int half = 0; half < 2; ++half) {
       printf(" waves %d-%d\n", half * 2, half * 2 + 1);
       for (int i = 0; i < 12; ++i) {
