@@ -55,6 +55,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kq = lane >> 4;
   const int nwg = CRS_NSTREAMS;
+  WP_DECL;
   const bool wave_active = (CRS_QBLOCK * 64 + wave * 16) < a.nq;
   float* sbuf = sbuf_all + wave * (L * 64);
   int* ibuf = ibuf_all + wave * (L * 64);
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   };
   auto park_tile = [&](int buf) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WP_LAP(5);   // wait for the look-ahead tile
 #pragma unroll
     for (int j = 0; j < C::kLoads; ++j) {
       u32x4 x = st[j];
@@ -207,13 +209,15 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
 
   park_tile(0);
   __syncthreads();
+  WP_LAP(0);   // prologue
 
   int cur = 0;
   for (; t < a.n_tiles; t += nwg) {
     f32x4 sc_use[C::kRt];
 #pragma unroll
     for (int rt = 0; rt < C::kRt; ++rt) sc_use[rt] = sc_cur[rt];
-    load_tile(t + nwg);
+    load_tile(t + nwg);   // unconditional (clamped past the end): no branch between an asm load and its wait
+    WP_LAP(1);   // look-ahead issue
     if (tau_pub) {
       unsigned x;
       asm volatile("global_load_dword %0, %1, off sc1" : "=v"(x) : "v"(tau_pub) : "memory");
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
           acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, qhi[ks], acc_hi, 0, 0, 0);
           acc_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, qlo[ks], acc_lo, 0, 0, 0);
         }
+        WP_LAP(3);   // fragment reads + MFMA
         const int row0 = t * TR + rt * 16 + kq * 4;
         const f32x4 rsc = sc_use[rt];
 #pragma unroll
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
           const float sc = ((float)acc_hi[i] * 256.0f + (float)acc_lo[i]) * qscale * rsc[i];
           const int row = row0 + i;
           if constexpr (TBK >= 0) {
-            best = (row < a.n_rows) ? fmaxf(best, sc) : best;
+            best = (t < n_full || row < a.n_rows) ? fmaxf(best, sc) : best;   // t < n_full is uniform: full tiles skip the row test
           } else if (sc > tau && row < a.n_rows) {
             sbuf[cnt * 64 + lane] = sc;
             ibuf[cnt * 64 + lane] = row;
@@ -261,13 +266,16 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
         }
       }
     }
+    WP_LAP(4);   // scores + selection
     park_tile(cur ^ 1);
+    WP_LAP(6);   // LDS store
     if (tau_pub) {
       unsigned x = tg;
       asm volatile("" : "+v"(x));
       tau = fmaxf(tau, foreign_tau(x));
     }
     __syncthreads();
+    WP_LAP(7);   // barrier
     cur ^= 1;
     ++it;
   }
@@ -291,6 +299,8 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
       }
     }
   }
+  WP_LAP(10);
+  WP_STORE(kWaves);
 }
 
 template <int D, int TR, int L, int TBK>

@@ -171,11 +171,11 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   WP_LAP(0);   // prologue
 
   int cur = 0, it = 0;
-  // one iteration: tile t sits in LDS buffer `cur`; tile t + nwg is fetched while t is multiplied (no loads past
-  // the stream's end: they would only queue behind everybody else's)
+  // one iteration: tile t sits in LDS buffer `cur`; tile t + nwg is fetched while t is multiplied.  The loads are
+  // issued unconditionally (past the stream's end they are clamped re-reads of the slab's last 16 bytes): a branch
+  // around an asm load would let the compiler put register copies between the load and its wait.
   while (t < tend) {
-    const bool has1 = t + tstep < tend;
-    if (has1) load_tile(t + tstep);
+    load_tile(t + tstep);
     WP_LAP(1);   // look-ahead issue
 #if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT <= 2   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either, 3: fragment reads without MFMA, 4: MFMA without fragment reads) */
     if (false) {
@@ -219,12 +219,10 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
       }
     }
     WP_LAP(4);   // selection
-    if (has1) {
-      park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
-      WP_LAP(6);   // LDS store
-      __syncthreads();
-      WP_LAP(7);   // barrier
-    }
+    park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
+    WP_LAP(6);   // LDS store
+    __syncthreads();
+    WP_LAP(7);   // barrier
     cur ^= 1;
     ++it;
     t += tstep;
