@@ -27,6 +27,8 @@
 namespace crs {
 namespace {
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <int D, int TR, int NW>
 struct TbCfg {
   static constexpr int kT = NW * 64;
@@ -60,56 +62,42 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   const int qbase = CRS_QBLOCK * (NW * 16) + wave * 16;
   const bool wave_active = qbase < a.nq;
 
-  int lds_dst[C::kLoads];
+  // ---- tile transfer: global memory -> LDS directly (global_load_lds_dwordx4, 16 bytes per lane; no staging
+  // registers, no LDS stores).  The LDS side of the transfer is linear -- position P = j * kT + tid of the tile
+  // buffer -- so the XOR swizzle of the 16-byte chunks is applied on the SOURCE side: P receives chunk swz(P).
+  // Written in asm: the compiler's own waitcnt insertion puts a vmcnt(0) in front of every LDS read that may alias
+  // an in-flight transfer, i.e. in front of every fragment read.
+  unsigned src_off[C::kLoads];
 #pragma unroll
   for (int j = 0; j < C::kLoads; ++j) {
     const int P = j * kT + tid;
-    const int r = P / C::kCpr, c = P % C::kCpr;
-    lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+    const int r = P / C::kCpr, cp = P % C::kCpr;
+    src_off[j] = (unsigned)(r * C::kCpr + ((cp & ~15) | ((cp ^ r) & 15))) * 16u;
   }
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
   const int n_full = a.n_rows / TR;
-  u32x4 st[C::kLoads];   // the look-ahead tile on its way to LDS
-  auto load_tile = [&](int tile_) {
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)tile_buf + (unsigned)wave * 1024u);
+  auto dma_tile = [&](int tile_, int buf) {
     const int tile = __builtin_amdgcn_readfirstlane(tile_);
+    const unsigned dst0 = lds_wave + (unsigned)(buf * C::kTileBytes);
     if (tile < n_full) {
       const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        const unsigned off = (unsigned)(j * kT + tid) * 16u;
-        u32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kT * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(src_off[j]), "s"(base) : "memory", "m0");
       }
-    } else {   // ragged last tile, or past the end: clamp every lane to the slab's last 16 bytes
+    } else {   // the ragged last tile: clamp every lane to the slab's last 16 bytes (rows past the end never rank)
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kT + tid) * 16;
+        size_t off = (size_t)tile * C::kTileBytes + src_off[j];
         off = off > last_chunk ? last_chunk : off;
         const char* p = slab + off;
-        u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kT * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(p) : "memory", "m0");
       }
     }
-  };
-  // wait for the look-ahead tile and move it into LDS
-  auto park_tile = [&](char* dst) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WP_LAP(5);   // wait for the tile's loads
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      u32x4 x = st[j];
-      asm volatile("" : "+v"(x));
-      st[j] = x;
-    }
-#if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT == 2
-    if (st[0][0] == 0x7fc01234u) *reinterpret_cast<u32x4*>(dst + lds_dst[0]) = st[0];   // keep the loads alive
-#else
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
-#endif
   };
 
 #ifdef CRS_TB_CONTIG   /* timing experiment (tools/scan_tb_probe): every stream walks ONE contiguous run of tiles */
@@ -120,7 +108,7 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   const int tstep = nwg, tend = a.n_tiles;
   int t = stream;
 #endif
-  load_tile(t);   // before the query fragments are fetched: the two latencies overlap
+  dma_tile(t, 0);   // before the query fragments are fetched: the two latencies overlap
   const int lr = lane & 15, kq = lane >> 4;
   const int qi = qbase + lr;
   const bool q_valid = qi < a.nq;
@@ -166,18 +154,17 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
     }
   };
 
-  park_tile(tile_buf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   WP_LAP(0);   // prologue
 
   int cur = 0, it = 0;
-  // one iteration: tile t sits in LDS buffer `cur`; tile t + nwg is fetched while t is multiplied.  The loads are
-  // issued unconditionally (past the stream's end they are clamped re-reads of the slab's last 16 bytes): a branch
-  // around an asm load would let the compiler put register copies between the load and its wait.
+  // one iteration: tile t sits in LDS buffer `cur`; tile t + nwg streams into the other buffer while t is multiplied
   while (t < tend) {
-    load_tile(t + tstep);
+    const bool has_next = t + tstep < tend;
+    if (has_next) dma_tile(t + tstep, cur ^ 1);
     WP_LAP(1);   // look-ahead issue
-#if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT <= 2   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 2: no LDS store either, 3: fragment reads without MFMA, 4: MFMA without fragment reads) */
+#if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT <= 2   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 3: fragment reads without MFMA, 4: MFMA without fragment reads) */
     if (false) {
 #else
     if (wave_active) {
@@ -219,10 +206,12 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
       }
     }
     WP_LAP(4);   // selection
-    park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
-    WP_LAP(6);   // LDS store
-    __syncthreads();
-    WP_LAP(7);   // barrier
+    if (has_next) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WP_LAP(5);   // wait for the look-ahead tile
+      __syncthreads();
+      WP_LAP(7);   // barrier
+    }
     cur ^= 1;
     ++it;
     t += tstep;
