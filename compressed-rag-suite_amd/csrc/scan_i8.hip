@@ -25,6 +25,7 @@ namespace crs {
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int D, int TR, int L>
 struct CfgI8 {
@@ -60,29 +61,29 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   float* sbuf = sbuf_all + wave * (L * 64);
   int* ibuf = ibuf_all + wave * (L * 64);
 
-  // ---- staging geometry (identical to the fp16 kernel: chunk P = j*256 + tid of the tile)
-  int lds_dst[C::kLoads];
+  // ---- tile transfer (as scan_tb.hip): global memory -> LDS directly; LDS position P = j * 256 + tid receives the
+  // tile's chunk swz(P) (the swizzle is applied on the source side, the LDS side of the transfer is linear)
+  unsigned src_off[C::kLoads];
 #pragma unroll
   for (int j = 0; j < C::kLoads; ++j) {
     const int P = j * kThreads + tid;
     const int r = P / C::kCpr, c = P % C::kCpr;
-    lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+    src_off[j] = (unsigned)(r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16u;
   }
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)tile_buf + (unsigned)wave * 1024u);
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * D - 16;
   const int n_full = a.n_rows / TR;
 
-  u32x4 st[C::kLoads];
   f32x4 sc_next[C::kRt], sc_cur[C::kRt];
-  auto load_tile = [&](int tile) {
+  auto load_tile = [&](int tile, int buf) {
+    const unsigned dst0 = lds_wave + (unsigned)(buf * C::kTileBytes);
     if (tile < n_full) {
       const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        const unsigned off = (unsigned)(j * kThreads + tid) * 16u;
-        u32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kThreads * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(src_off[j]), "s"(base) : "memory", "m0");
       }
       const float* sb = uniform_ptr(a.scales + (size_t)tile * TR);   // this lane's rows 16 rt + 4 kq .. +3
 #pragma unroll
@@ -95,12 +96,11 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     } else {
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
+        size_t off = (size_t)tile * C::kTileBytes + src_off[j];
         off = off > last_chunk ? last_chunk : off;
         const char* p = slab + off;
-        u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kThreads * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(p) : "memory", "m0");
       }
 #pragma unroll
       for (int rt = 0; rt < C::kRt; ++rt) {
@@ -117,28 +117,20 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
       }
     }
   };
-  auto park_tile = [&](int buf) {
+  // wait for the look-ahead tile (in LDS once vmcnt says so) and take over its row scales
+  auto park_tile = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WP_LAP(5);   // wait for the look-ahead tile
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      u32x4 x = st[j];
-      asm volatile("" : "+v"(x));
-      st[j] = x;
-    }
 #pragma unroll
     for (int rt = 0; rt < C::kRt; ++rt) {
       f32x4 x = sc_next[rt];
       asm volatile("" : "+v"(x));
       sc_cur[rt] = x;
     }
-    char* dst = tile_buf + buf * C::kTileBytes;
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };
 
   int t = CRS_STREAM;
-  load_tile(t);
+  load_tile(t, 0);
 
   // ---- this wave's queries -> 16-bit fixed point -> two int8 digit planes, resident in VGPRs.
   // B operand of v_mfma_i32_16x16x64_i8: lane holds query (lane & 15), k = 64 ks + 16 kq + j, j = 0..15.
@@ -207,7 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   };
   const size_t po = ((size_t)(q_valid ? qi : 0) * nwg + CRS_STREAM) * a.kp;   // this query's partial list [nq, nwg, kp]
 
-  park_tile(0);
+  park_tile();
   __syncthreads();
   WP_LAP(0);   // prologue
 
@@ -216,7 +208,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     f32x4 sc_use[C::kRt];
 #pragma unroll
     for (int rt = 0; rt < C::kRt; ++rt) sc_use[rt] = sc_cur[rt];
-    load_tile(t + nwg);   // unconditional (clamped past the end): no branch between an asm load and its wait
+    load_tile(t + nwg, cur ^ 1);   // unconditional (clamped past the end): the row scales are asm loads into registers
     WP_LAP(1);   // look-ahead issue
     if (tau_pub) {
       unsigned x;
@@ -267,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
       }
     }
     WP_LAP(4);   // scores + selection
-    park_tile(cur ^ 1);
+    park_tile();
     WP_LAP(6);   // LDS store
     if (tau_pub) {
       unsigned x = tg;
