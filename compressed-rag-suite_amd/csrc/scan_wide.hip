@@ -146,11 +146,48 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
   const bool q_valid = qi < a.nq;
   f16x8 qf[C::kKsteps];
   {
-    const _Float16* qrow = a.q + (size_t)(q_valid ? qi : 0) * D + h * 8;
+    // Fetched straight into this layout a load instruction touches 32 rows x 2 pieces of 16 bytes -- 64 cache
+    // lines per instruction, D/16 instructions per wave: 12 k cycles of the texture addresser per workgroup,
+    // 42 % of a 128-query launch over 100 k rows (tools/scan_wide_probe).  So the wave's 32 query rows come in
+    // as whole 128-byte column blocks (8 lanes per row), pass through a wave-private 4 KB of the still idle
+    // tile buffer (chunk XOR-swizzled by (row >> 1) & 7) and are read back as fragments.  LDS operations of a
+    // wave execute in order, so the block's reads see its writes and the next block's writes come after them.
+    constexpr int kBlocks = C::kCpr / 8;   // 128-byte column blocks of a query row
+    constexpr int kGroup = 3;              // blocks whose loads are in flight together (12 x 16 bytes per lane)
+    char* qs = tile_buf + wave * 4096;
+    const int q0 = qblock * (NW * 32) + wave * 32;
+    const char* qbytes = reinterpret_cast<const char*>(a.q);
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int ks = 0; ks < C::kKsteps; ++ks) {
-      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[ks] = q_valid ? *reinterpret_cast<const f16x8*>(qrow + ks * 16) : z;
+    for (int g0 = 0; g0 < kBlocks; g0 += kGroup) {
+      u32x4 tmp[kGroup * 4];
+#pragma unroll
+      for (int p = 0; p < kGroup; ++p) {
+        if (g0 + p < kBlocks) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = j * 64 + lane, q = c >> 3, col = c & 7;
+            const int qq = q0 + q < a.nq ? q0 + q : a.nq - 1;
+            tmp[p * 4 + j] = *reinterpret_cast<const u32x4*>(qbytes + (size_t)qq * (D * 2) + (g0 + p) * 128 + col * 16);
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < kGroup; ++p) {
+        if (g0 + p < kBlocks) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = j * 64 + lane, q = c >> 3, col = c & 7;
+            *reinterpret_cast<u32x4*>(qs + q * 128 + ((col ^ ((q >> 1) & 7)) * 16)) = tmp[p * 4 + j];
+          }
+#pragma unroll
+          for (int ksl = 0; ksl < 4; ++ksl) {
+            const int col = 2 * ksl + h;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(qs + qn * 128 + ((col ^ ((qn >> 1) & 7)) * 16));
+            qf[(g0 + p) * 4 + ksl] = q_valid ? v : z;
+          }
+        }
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < C::kKsteps; ++ks) {   // retire these loads here, not somewhere in the loop
@@ -187,6 +224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
   };
 
   if constexpr (PF == 2) load_tile(st1, t + nwg);   // after the query loads: park_tile's counted wait then covers st0 + queries
+  __syncthreads();   // every wave has its fragments: the tile buffer may now take the first tile
   park_tile(st0, tile_buf);
   __syncthreads();
   WP_LAP(0);   // prologue
