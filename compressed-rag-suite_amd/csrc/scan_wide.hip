@@ -38,6 +38,7 @@ int scan_wide_slots(int k);
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 
 
@@ -57,20 +58,16 @@ struct WCfg {
   static constexpr int kTileBytes = TR * D * 2;
   static constexpr int kLoads = kTileBytes / (kThreadsW * 16);
   static constexpr int kKsteps = D / 16;
-  static constexpr int kLds = 2 * kTileBytes;
+  static constexpr int kQStage = NW * 4096;   // prologue: 4 KB per wave for the query transpose, in the second tile buffer
+  static constexpr int kLds = 2 * kTileBytes > kTileBytes + kQStage ? 2 * kTileBytes : kTileBytes + kQStage;
   static_assert(D % 128 == 0, "row length must be a multiple of 128 elements");
   static_assert(kTileBytes % (kThreadsW * 16) == 0, "tile must split into whole 16-byte loads");
 };
 
-// PF = tiles in flight per workgroup: 2 for the 8-wave configuration (one workgroup per CU) where the
-// registers allow it, else 1 (two workgroups per CU, or D = 512 whose query fragments fill the file).
-template <int D, int NW>
-constexpr int wide_pf() { return 1; }   // 2 measured no faster (the kernel was barrier-bound, below) and doubles the code
-
+// (one look-ahead tile per workgroup: a second one measured no faster -- the kernel is LDS- / barrier-bound, below)
 template <int D, int NW, int K>
 __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a) {
   using C = WCfg<D, NW>;
-  constexpr int PF = wide_pf<D, NW>();
   constexpr int kT = C::kThreadsW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tile_buf = smem;
@@ -82,62 +79,45 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
   WP_DECL;
   const bool wave_active = (qblock * (NW * 32) + wave * 32) < a.nq;   // wave-uniform
 
-  // staging geometry: load j of this thread covers 16-byte chunk P = j * kT + tid of the tile
-  int lds_dst[C::kLoads];
+  // tile transfer as in scan_tb.hip: global memory -> LDS directly, LDS position P = j * kT + tid receives the
+  // tile's chunk swz(P) (source-side swizzle); asm, because the compiler would wait for every transfer before
+  // every fragment read
+  unsigned src_off[C::kLoads];
 #pragma unroll
   for (int j = 0; j < C::kLoads; ++j) {
     const int P = j * kT + tid;
-    const int r = P / C::kCpr, c = P % C::kCpr;
-    lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+    const int r = P / C::kCpr, cp = P % C::kCpr;
+    src_off[j] = (unsigned)(r * C::kCpr + ((cp & ~15) | ((cp ^ r) & 15))) * 16u;
   }
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
   constexpr int RB = C::RB, WTR = C::TR;
   const int n_full = a.n_rows / WTR;
-
-  // Two register staging sets: while tile i is being multiplied out of LDS, tiles i+1 AND i+2 are in
-  // flight (one tile ahead leaves 24 KB per CU in flight at one workgroup per CU, and the kernel then
-  // runs at the memory latency: measured 2.4 TB/s on C4 with 256 queries).
-  u32x4 st0[C::kLoads], st1[PF == 2 ? C::kLoads : 1];
-  auto load_tile = [&](auto& st, int tile_) {
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)tile_buf + (unsigned)wave * 1024u);
+  auto dma_tile = [&](int tile_, int buf) {
     const int tile = __builtin_amdgcn_readfirstlane(tile_);
+    const unsigned dst0 = lds_wave + (unsigned)(buf * C::kTileBytes);
     if (tile < n_full) {
       const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        const unsigned off = (unsigned)(j * kT + tid) * 16u;
-        u32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kT * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(src_off[j]), "s"(base) : "memory", "m0");
       }
-    } else {   // ragged last tile, or past the end: clamp every lane to the slab's last 16 bytes
+    } else {   // the ragged last tile: clamp every lane to the slab's last 16 bytes (rows past the end never rank)
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kT + tid) * 16;
+        size_t off = (size_t)tile * C::kTileBytes + src_off[j];
         off = off > last_chunk ? last_chunk : off;
         const char* p = slab + off;
-        u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kT * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(p) : "memory", "m0");
       }
     }
-  };
-  // wait until all but the youngest tile's loads have landed (vmcnt counts in issue order), then move
-  // this set into LDS
-  auto park_tile = [&](auto& st, char* dst) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF == 2 ? C::kLoads : 0) : "memory");
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      u32x4 x = st[j];
-      asm volatile("" : "+v"(x));
-      st[j] = x;
-    }
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };
 
   int t = stream;
-  load_tile(st0, t);   // goes out before the query fragments are fetched, so the two latencies overlap
+  dma_tile(t, 0);   // goes out before the query fragments are fetched, so the two latencies overlap
 
   // ---- this wave's 32 queries, full depth, as B fragments: lane (n = l & 31, h = l >> 5) holds
   // Q[n][16 ks + 8 h .. + 8] for every k-step
@@ -150,11 +130,11 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
     // lines per instruction, D/16 instructions per wave: 12 k cycles of the texture addresser per workgroup,
     // 42 % of a 128-query launch over 100 k rows (tools/scan_wide_probe).  So the wave's 32 query rows come in
     // as whole 128-byte column blocks (8 lanes per row), pass through a wave-private 4 KB of the still idle
-    // tile buffer (chunk XOR-swizzled by (row >> 1) & 7) and are read back as fragments.  LDS operations of a
+    // SECOND tile buffer (chunk XOR-swizzled by (row >> 1) & 7) and are read back as fragments.  LDS operations of a
     // wave execute in order, so the block's reads see its writes and the next block's writes come after them.
     constexpr int kBlocks = C::kCpr / 8;   // 128-byte column blocks of a query row
     constexpr int kGroup = 3;              // blocks whose loads are in flight together (12 x 16 bytes per lane)
-    char* qs = tile_buf + wave * 4096;
+    char* qs = tile_buf + C::kTileBytes + wave * 4096;
     const int q0 = qblock * (NW * 32) + wave * 32;
     const char* qbytes = reinterpret_cast<const char*>(a.q);
     const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -223,10 +203,8 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
     }
   };
 
-  if constexpr (PF == 2) load_tile(st1, t + nwg);   // after the query loads: park_tile's counted wait then covers st0 + queries
-  __syncthreads();   // every wave has its fragments: the tile buffer may now take the first tile
-  park_tile(st0, tile_buf);
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // the first tile has landed, and every wave has its fragments: the second buffer is free
   WP_LAP(0);   // prologue
 
   // Stagger (MI355X_MICROARCH.md, "two waves per SIMD", item 9).  Waves w and w + 4 share a SIMD, and with
@@ -290,9 +268,9 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
   };
 
   int cur = 0, it = 0;
-  // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg is in flight in `sx`, `sy` is free
-  auto body = [&](auto& sx, auto& sy) {
-    if constexpr (PF == 2) load_tile(sy, t + 2 * nwg); else load_tile(sx, t + nwg);
+  // one iteration: tile t sits in LDS buffer `cur`, tile t + nwg streams into the other one
+  while (t < a.n_tiles) {
+    if (t + nwg < a.n_tiles) dma_tile(t + nwg, cur ^ 1);
     if (wave_active) {
       WP_LAP(1);   // tile-load issue
       const char* buf = tile_buf + cur * C::kTileBytes;
@@ -308,24 +286,14 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_wide_kernel(const ScanArgs a)
       }
     }
     WP_LAP(4);   // selection (waves 0..3)
-    park_tile(sx, tile_buf + (cur ^ 1) * C::kTileBytes);
-    WP_LAP(6);   // wait for the next tile + LDS store
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WP_LAP(6);   // wait for the next tile
     __syncthreads();
     WP_LAP(7);   // barrier
     cur ^= 1;
     ++it;
     t += nwg;
-  };
-  if constexpr (PF == 2) {
-    while (t < a.n_tiles) {
-      body(st1, st0);
-      if (t >= a.n_tiles) break;
-      body(st0, st1);
-    }
-  } else {
-    while (t < a.n_tiles) body(st0, st0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail prefetches (clamped re-reads) must not outlive the kernel's registers
 
   if (wave_active && late && it > 0) select(acc_prev, t - nwg, it - 1);   // the deferred last tile
   if (wave_active && (it & 1)) insert(px, pr);   // odd tile count: the last (even) tile is still pending
