@@ -26,6 +26,7 @@ int scan_wide_slots(int k);
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int D>
 struct KsCfg {
@@ -57,55 +58,43 @@ __global__ __launch_bounds__(512, 2) void scan_wide_ks_kernel(const ScanArgs a) 
   const int qblock = CRS_QBLOCK, stream = CRS_STREAM;
   const bool wave_active = (qblock * 128 + pair * 32) < a.nq;   // wave-uniform
 
-  int lds_dst[C::kLoads];
+  // tile transfer as in scan_tb.hip: global memory -> LDS directly (source-side swizzle, asm)
+  unsigned src_off[C::kLoads];
 #pragma unroll
   for (int j = 0; j < C::kLoads; ++j) {
     const int P = j * kT + tid;
-    const int r = P / C::kCpr, c = P % C::kCpr;
-    lds_dst[j] = (r * C::kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+    const int r = P / C::kCpr, cp = P % C::kCpr;
+    src_off[j] = (unsigned)(r * C::kCpr + ((cp & ~15) | ((cp ^ r) & 15))) * 16u;
   }
   const char* slab = reinterpret_cast<const char*>(a.slab);
   const size_t last_chunk = (size_t)a.n_rows * (D * 2) - 16;
   const int n_full = a.n_rows / 32;
-  // (a second register staging set -- two tiles in flight -- measured no faster here: 592 vs 558 us on C3)
-  u32x4 st[C::kLoads];
-  auto load_tile = [&](int tile_) {
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)tile_buf + (unsigned)wave * 1024u);
+  // (a second look-ahead tile measured no faster here: 592 vs 558 us on C3)
+  auto dma_tile = [&](int tile_, int buf) {
     const int tile = __builtin_amdgcn_readfirstlane(tile_);
+    const unsigned dst0 = lds_wave + (unsigned)(buf * C::kTileBytes);
     if (tile < n_full) {
       const char* base = uniform_ptr(slab + (size_t)tile * C::kTileBytes);
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        const unsigned off = (unsigned)(j * kT + tid) * 16u;
-        u32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kT * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(src_off[j]), "s"(base) : "memory", "m0");
       }
-    } else {   // ragged last tile, or past the end: clamp every lane to the slab's last 16 bytes
+    } else {   // the ragged last tile: clamp every lane to the slab's last 16 bytes (rows past the end never rank)
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
-        size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kT + tid) * 16;
+        size_t off = (size_t)tile * C::kTileBytes + src_off[j];
         off = off > last_chunk ? last_chunk : off;
         const char* p = slab + off;
-        u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-        st[j] = x;
+        const unsigned dst = dst0 + (unsigned)(j * kT * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(p) : "memory", "m0");
       }
     }
-  };
-  auto park_tile = [&](char* dst) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) {
-      u32x4 x = st[j];
-      asm volatile("" : "+v"(x));
-      st[j] = x;
-    }
-#pragma unroll
-    for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };
 
   int t = stream;
-  load_tile(t);
+  dma_tile(t, 0);
 
   // ---- this wave's half of its pair's 32 queries: lane (n, h) holds Q[n][kh DH + 16 ks + 8 h .. + 8]
   const int qn = lane & 31, h = lane >> 5;
@@ -179,13 +168,13 @@ __global__ __launch_bounds__(512, 2) void scan_wide_ks_kernel(const ScanArgs a) 
     }
   };
 
-  park_tile(tile_buf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int cur = 0, it = 0;
   for (; t < a.n_tiles; t += nwg) {
-    load_tile(t + nwg);
+    if (t + nwg < a.n_tiles) dma_tile(t + nwg, cur ^ 1);
     if (wave_active) {
       const char* buf = tile_buf + cur * C::kTileBytes;
       if (kh == 0) {   // last tile's selection (the partner's half-sums are behind the barrier), then this tile's MFMAs
@@ -198,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void scan_wide_ks_kernel(const ScanArgs a) 
         for (int r = 0; r < 16; ++r) xb[r * 64] = acc[r];
       }
     }
-    park_tile(tile_buf + (cur ^ 1) * C::kTileBytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
     ++it;
