@@ -75,7 +75,12 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   const size_t last_chunk = (size_t)a.n_rows * D - 16;
   const int n_full = a.n_rows / TR;
 
-  f32x4 sc_next[C::kRt], sc_cur[C::kRt];
+  // the tile's TR row scales travel the same way, into a 128-byte slot per tile buffer behind everything else: ONE
+  // 16-byte-per-lane transfer by wave 0 instead of two register loads in every wave (a load instruction costs a wave
+  // ~200 cycles of issue under memory back-pressure, and the iteration is issue time + latency)
+  constexpr int kScOff = TBK < 0 ? C::kLds : 2 * C::kTileBytes;
+  char* sc_lds = smem + kScOff;
+  const unsigned sc_m0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)sc_lds);
   auto load_tile = [&](int tile, int buf) {
     const unsigned dst0 = lds_wave + (unsigned)(buf * C::kTileBytes);
     if (tile < n_full) {
@@ -85,13 +90,10 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
         const unsigned dst = dst0 + (unsigned)(j * kThreads * 16);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(src_off[j]), "s"(base) : "memory", "m0");
       }
-      const float* sb = uniform_ptr(a.scales + (size_t)tile * TR);   // this lane's rows 16 rt + 4 kq .. +3
-#pragma unroll
-      for (int rt = 0; rt < C::kRt; ++rt) {
-        const unsigned off = (unsigned)(rt * 16 + kq * 4) * 4u;
-        f32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(sb) : "memory");
-        sc_next[rt] = x;
+      if (wave == 0 && lane < TR / 4) {
+        const float* sb = uniform_ptr(a.scales + (size_t)tile * TR);
+        const unsigned off = (unsigned)lane * 16u, dst = sc_m0 + (unsigned)(buf * (TR * 4));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(sb) : "memory", "m0");
       }
     } else {
 #pragma unroll
@@ -102,31 +104,16 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
         const unsigned dst = dst0 + (unsigned)(j * kThreads * 16);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(p) : "memory", "m0");
       }
-#pragma unroll
-      for (int rt = 0; rt < C::kRt; ++rt) {
-        f32x4 x;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const long row = min((long)tile * TR + rt * 16 + kq * 4 + i, (long)a.n_rows - 1);
-          const float* p = a.scales + row;
-          float y;
-          asm volatile("global_load_dword %0, %1, off" : "=v"(y) : "v"(p) : "memory");
-          x[i] = y;
-        }
-        sc_next[rt] = x;
+      if (wave == 0 && lane < TR) {   // the slab's one ragged tile (or past the end): ordinary loads, clamped rows
+        const long row = min((long)tile * TR + lane, (long)a.n_rows - 1);
+        reinterpret_cast<float*>(sc_lds + buf * (TR * 4))[lane] = a.scales[row];
       }
     }
   };
-  // wait for the look-ahead tile (in LDS once vmcnt says so) and take over its row scales
+  // wait for the look-ahead tile and its scales (in LDS once vmcnt says so)
   auto park_tile = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WP_LAP(5);   // wait for the look-ahead tile
-#pragma unroll
-    for (int rt = 0; rt < C::kRt; ++rt) {
-      f32x4 x = sc_next[rt];
-      asm volatile("" : "+v"(x));
-      sc_cur[rt] = x;
-    }
   };
 
   int t = CRS_STREAM;
@@ -207,8 +194,9 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   for (; t < a.n_tiles; t += nwg) {
     f32x4 sc_use[C::kRt];
 #pragma unroll
-    for (int rt = 0; rt < C::kRt; ++rt) sc_use[rt] = sc_cur[rt];
-    load_tile(t + nwg, cur ^ 1);   // unconditional (clamped past the end): the row scales are asm loads into registers
+    for (int rt = 0; rt < C::kRt; ++rt)   // this lane's rows 16 rt + 4 kq .. + 3
+      sc_use[rt] = *reinterpret_cast<const f32x4*>(sc_lds + cur * (TR * 4) + (rt * 16 + kq * 4) * 4);
+    if (t + nwg < a.n_tiles) load_tile(t + nwg, cur ^ 1);
     WP_LAP(1);   // look-ahead issue
     if (tau_pub) {
       unsigned x;
@@ -298,7 +286,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
 template <int D, int TR, int L, int TBK>
 int launch_i8(const ScanArgs& a, hipStream_t stream) {
   using C = CfgI8<D, TR, L>;
-  constexpr int lds = TBK < 0 ? C::kLds : 2 * C::kTileBytes;
+  constexpr int lds = (TBK < 0 ? C::kLds : 2 * C::kTileBytes) + 2 * TR * 4;   // + the row-scale slots
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<D, TR, L, TBK>),
