@@ -4,21 +4,31 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: launched by
 torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
-A "step" is one query batch through the retrieve path with everything resident in HBM:
-  query encoder forward (token ids [Qb, 16] -> fp32 sentence embeddings; MFMA GEMMs + attention)
-  -> normalise + fp16 cast -> exact cosine scan of this rank's slab shard + in-kernel top-k
-  -> per-workgroup list merge -> (N > 1) RCCL all-gather of the per-shard top-k + final merge.
-The encoder has the architecture BASELINE.json names for the workload (all-MiniLM-L6-v2 for the
-384-d configs, bge-base-en-v1.5 for the 768-d ones) with seeded random weights and synthetic token
-ids (no checkpoints offline).
+One query BATCH through the retrieve path, everything resident in HBM:
+  query encoder forward (token ids [Qb, 16] -> fp32 sentence embeddings + the scan's fp16 query block)
+  -> exact cosine scan of this rank's slab shard, over-fetching k' = 16 candidates per query
+  -> per-workgroup list merge + tile refine -> fp32 re-rank of the k' candidates against the fp32 shadow
+     of the shard (the ranking the reference's fp32 ChromaDB collection gives), best k = 10 written
+     straight into this rank's wire block
+  -> (N > 1) ONE RCCL all-gather of the wire blocks + k-way merge on every rank.
+A STEP is one such batch on each of the S in-flight HIP streams (S = --streams), so the timed region is
+steady state whatever --steps is; queries per step = S x Qb.
 
 Workloads (BASELINE.json configs; --workload):
-  c2  100k x 384 fp16 slab per GPU, 64 queries per rank per step, k=10   (default; configs[1])
-  c3  1M x 768 fp16, 256 queries
-  c4  10M x 384 fp16 sharded: 1.25M rows per GPU (the 8-GPU shard size), 64 queries per rank
-  c5  as c4 with an int8 768-d slab
-Scaling is weak: the per-GPU shard and the per-rank query batch are fixed; the corpus and the
-global query batch grow with N (every rank scans its shard for all N*Qb queries of the step).
+  c4  10M x 384 fp16 corpus, global 64-query batches, k=10      (default: the configuration the metric is quoted on)
+  c5  10M x 768 int8 (+fp32 row scales) corpus, fp16 queries, 64-query batches
+  c3  1M x 768 fp16, 256-query batches
+  c2  100k x 384 fp16, 64-query batches (Infinity-Cache resident: a latency case, not an HBM measurement)
+  enc-minilm / enc-bge   the index-build side: encoder forward over full-length chunks (tokens/s, MFMA fraction)
+Scaling is STRONG by default: the corpus is fixed and split into N contiguous
+row shards (10M / N rows per GPU), the global query batch is fixed, every rank encodes the whole batch
+(replicated: no query exchange) and scans its shard for all of it.  --scaling weak keeps the round-1
+behaviour (fixed 1.25M-row shard and Qb queries PER RANK; queries are all-gathered first).
+
+The encoder has the architecture BASELINE.json names for the workload (all-MiniLM-L6-v2 for the 384-d
+configs, bge-base-en-v1.5 for the 768-d ones) with seeded random weights and synthetic token ids (no
+checkpoints offline).  Recall@10 is measured against the exact ranking of the UNQUANTISED fp32 rows
+(fp64 accumulation), not against the quantised slab.
 """
 from __future__ import annotations
 
@@ -37,46 +47,145 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "compressed-rag-suite_amd"))
 
 WORKLOADS = {
-    #        rows/GPU   dim  Qb   k  slab  encoder
-    "c2": (100_000, 384, 64, 10, "f16", "minilm"),
-    "c3": (1_000_000, 768, 256, 10, "f16", "bge"),
-    "c4": (1_250_000, 384, 64, 10, "f16", "minilm"),
-    "c5": (1_250_000, 768, 64, 10, "i8", "bge"),
+    #       corpus rows   dim  Qb   k  slab  encoder   rows/GPU in weak mode
+    "c2": (100_000, 384, 64, 10, "f16", "minilm", 100_000),
+    "c3": (1_000_000, 768, 256, 10, "f16", "bge", 1_000_000),
+    "c4": (10_000_000, 384, 64, 10, "f16", "minilm", 1_250_000),
+    "c5": (10_000_000, 768, 64, 10, "i8", "bge", 1_250_000),
 }
+ENC_WORKLOADS = {"enc-minilm": ("minilm", 256, 256), "enc-bge": ("bge", 64, 512)}   # (arch, chunks per batch, tokens per chunk)
 QUERY_TOKENS = 16
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+K_SCAN = 16               # candidates the scan over-fetches for the fp32 re-rank
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TF = {"f16": 2500.0, "i8": 5000.0}
 
 
-def synth_shard(torch, n, dim, seed, device, chunk=250_000):
-    """Seeded unit-normalised Gaussian rows, generated on the device in chunks (fp32)."""
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def synth_rows(torch, n, dim, seed, device, chunk=250_000):
+    """Seeded Gaussian rows, generated on the device in chunks (fp32; the slab append normalises)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     for lo in range(0, n, chunk):
         m = min(chunk, n - lo)
-        x = torch.randn((m, dim), generator=g, device=device, dtype=torch.float32)
-        yield lo, x
+        yield lo, torch.randn((m, dim), generator=g, device=device, dtype=torch.float32)
+
+
+def exact_topk_f64(torch, q32, shadow, rows, k, id_base, block=200_000):
+    """Ground truth: top-k of <q, row> over the UNQUANTISED fp32 rows with fp64 accumulation
+    (score desc, id asc) -- the ranking an exact fp32 store such as the reference's returns."""
+    nq = q32.shape[0]
+    best_s = torch.full((nq, k), float("-inf"), dtype=torch.float64, device=q32.device)
+    best_i = torch.full((nq, k), -1, dtype=torch.int64, device=q32.device)
+    q64 = q32.double()
+    for lo in range(0, rows, block):
+        hi = min(rows, lo + block)
+        sc = q64 @ shadow[lo:hi].double().T
+        ts, ti = sc.topk(min(k, hi - lo), dim=1)
+        cat_s = torch.cat([best_s, ts], 1)
+        cat_i = torch.cat([best_i, ti + lo + id_base], 1)
+        # order: score desc, id asc (stable sort by id first, then by score)
+        o = torch.argsort(cat_i, dim=1, stable=True)
+        cat_s, cat_i = torch.gather(cat_s, 1, o), torch.gather(cat_i, 1, o)
+        o = torch.argsort(cat_s, dim=1, descending=True, stable=True)[:, :k]
+        best_s, best_i = torch.gather(cat_s, 1, o), torch.gather(cat_i, 1, o)
+    return best_s, best_i
+
+
+def recall_rows(got_i, ref_i):
+    """Recall@k per query: |got ∩ ref| / |ref| (reference evaluation/retrieval/retrieval_metrics.py:49-58)."""
+    hits = (got_i.unsqueeze(2) == ref_i.unsqueeze(1)) & (ref_i.unsqueeze(1) >= 0)
+    return hits.any(dim=1).float().sum(1) / (ref_i >= 0).float().sum(1).clamp(min=1)
+
+
+def bench_encoder(args, torch, nat, dev, rank, world, dist):
+    """--workload enc-*: the index-build side of the path (EmbeddingModel.embed_chunks, reference
+    rag/embedding.py:75-87): full-length synthetic chunks through the encoder, tokens/s and MFMA fraction."""
+    import numpy as np
+    from rag._encoder import HipEncoder, ModelShape
+    from rag.embedding import _KNOWN, synthetic_weights
+    arch_name, batch, seq = ENC_WORKLOADS[args.workload]
+    arch = _KNOWN["all-minilm-l6-v2" if arch_name == "minilm" else "bge-base-en-v1.5"]
+    shape = ModelShape(ln_eps=1e-12, **arch)
+    seq = min(seq, shape.max_seq)
+    enc = HipEncoder(shape, synthetic_weights(shape, seed=7), device=dev)
+    rng = np.random.default_rng(4321 + rank)
+    ids_h = rng.integers(1000, shape.vocab_size, size=(batch, seq)).astype(np.int32)
+    ids_h[:, 0], ids_h[:, -1] = 101, 102
+    ids_d = torch.from_numpy(ids_h).to(dev)
+    lens_d = torch.full((batch,), seq, dtype=torch.int32, device=dev)
+    out = torch.empty((batch, shape.hidden), dtype=torch.float32, device=dev)
+    ws = torch.empty(enc.workspace_bytes(batch, seq), dtype=torch.uint8, device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        enc.forward(ids_d, lens_d, out=out, workspace=ws)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.forward(ids_d, lens_d, out=out, workspace=ws)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tokens = batch * seq
+    h, f, nl = shape.hidden, shape.ffn, shape.layers
+    flops = tokens * nl * (2 * (4 * h * h + 2 * h * f)) + nl * 4 * seq * h * tokens   # projections + QK^T + PV
+    ms = dt / args.steps * 1e3
+    tf = flops / (ms * 1e-3) / 1e12
+    if rank == 0:
+        print(json.dumps({
+            "metric": "index-build encoder tokens/sec (EmbeddingModel.embed_chunks forward, full-length chunks)",
+            "value": round(tokens * world * args.steps / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 x f16 -> f32", "data": "synthetic",
+            "config": {"workload": args.workload, "encoder": ("all-MiniLM-L6-v2" if arch_name == "minilm" else "bge-base-en-v1.5")
+                       + " shape, seeded random weights", "chunks_per_step_per_gpu": batch, "tokens_per_chunk": seq},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TF["f16"], "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_PEAK_TF["f16"], 4), "traffic": None,
+                         "kernel": "whole forward (see profiles/r02_enc_*_kernel_stats.csv for the per-kernel split)",
+                         "algorithmic_flops": int(flops)},
+            "cpu_baseline": None}), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS) + sorted(ENC_WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--no-refine", action="store_true",
+                    help="time the plain fp16/int8 scan (k' = k, no fp32 shadow re-rank); recall vs fp32 is then < 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--scan-only", action="store_true", help="diagnostic: skip the encoder (NOT the metric)")
-    ap.add_argument("--streams", type=int, default=32,
-                    help="independent query batches in flight on separate HIP streams (1 GPU runs only)")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="query batches in flight, one HIP stream each; a step is one batch on every stream")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
-    ap.add_argument("--extra-launches", type=int, default=0,
-                    help="diagnostic: this many extra tiny kernels per step (what does one more launch cost?)")
-    ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the per-rank query batch size")
+    ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the query batch size")
+    ap.add_argument("--rows", type=int, default=0, help="diagnostic: override the corpus rows")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     from rag import _native as nat
+    from rag import _shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,19 +207,36 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    rows, dim, qb, k, slab_kind, enc_name = WORKLOADS[args.workload]
+    if args.workload in ENC_WORKLOADS:
+        bench_encoder(args, torch, nat, dev, rank, world, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    corpus_rows, dim, qb, k, slab_kind, enc_name, weak_rows = WORKLOADS[args.workload]
     if args.queries > 0:
         qb = args.queries
+    if args.rows > 0:
+        corpus_rows = weak_rows = args.rows
+    strong = args.scaling == "strong"
+    if strong:
+        lo_row, hi_row = _shard.shard_slice(corpus_rows, world, rank)
+        rows, id_base, nq_all = hi_row - lo_row, lo_row, qb
+    else:
+        rows, id_base, nq_all = weak_rows, rank * weak_rows, qb * world
+        corpus_rows = weak_rows * world
+    refine = not args.no_refine
+    k_scan = max(k, K_SCAN) if refine else k
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
     pd = nat.padded_dim(dim, slab_type)
-    id_base = rank * rows
 
-    # ---- index build (untimed): synthetic embeddings -> slab shard in HBM through the product path
+    # ---- index build (untimed): synthetic embeddings -> slab shard (+ fp32 shadow) in HBM through the product path
     slab = torch.empty((rows, pd), dtype=torch.int8 if slab_type == nat.SLAB_I8 else torch.float16, device=dev)
     scales = torch.empty(rows, dtype=torch.float32, device=dev) if slab_type == nat.SLAB_I8 else None
+    shadow = torch.empty((rows, dim), dtype=torch.float32, device=dev)   # unquantised rows: refine operand AND ground truth
     t_build = time.perf_counter()
-    for lo, x in synth_shard(torch, rows, dim, 1234 + rank, dev):
-        nat.slab_append_f32(x, slab, lo, slab_type, scales=scales)
+    for lo, x in synth_rows(torch, rows, dim, 1234 + rank, dev):
+        nat.slab_append_f32(x, slab, lo, slab_type, scales=scales, shadow=shadow)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
@@ -123,85 +249,101 @@ def main():
     shape = ModelShape(ln_eps=1e-12, **arch)
     enc_w = synthetic_weights(shape, seed=7)
     enc = HipEncoder(shape, enc_w, device=dev)
-    rng = np.random.default_rng(4321 + rank)
+    rng = np.random.default_rng(4321 + (0 if strong else rank))      # strong: every rank holds the SAME global batch
     ids_h = rng.integers(1000, shape.vocab_size, size=(qb, QUERY_TOKENS)).astype(np.int32)
     ids_h[:, 0], ids_h[:, -1] = 101, 102                      # [CLS] ... [SEP], no padding
     mask_h = np.ones((qb, QUERY_TOKENS), dtype=np.int32)
     ids_d = torch.from_numpy(ids_h).to(dev)
     lens_d = torch.from_numpy(mask_h.sum(1).astype(np.int32)).to(dev)
-    q32 = enc.forward(ids_d, lens_d).clone()
-    # plant a near neighbour of every even query into this rank's shard (50 % planted)
+    q32 = enc.forward(ids_d, lens_d).clone()                  # fp32 unit rows [qb, dim]
+    # plant a near neighbour of every even query (50 % planted); strong: query 2p lives on rank p % world
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
-    j = torch.randperm(rows, generator=g, device=dev)[: qb // 2]
-    planted = q32[0::2] + 0.1 * torch.randn((qb // 2, dim), generator=g, device=dev)
-    tmp = torch.empty((qb // 2, pd), dtype=slab.dtype, device=dev)
-    tmp_sc = torch.empty(qb // 2, dtype=torch.float32, device=dev) if scales is not None else None
-    nat.slab_append_f32(planted.contiguous(), tmp, 0, slab_type, scales=tmp_sc)
-    slab[j] = tmp
-    if scales is not None:
-        scales[j] = tmp_sc
-    nq_all = qb * world
+    mine = [p for p in range(0, qb, 2) if (not strong) or ((p // 2) % world == rank)]
+    if mine and rows > len(mine):
+        j = torch.randperm(rows, generator=g, device=dev)[: len(mine)]
+        planted = q32[mine] + 0.1 * torch.randn((len(mine), dim), generator=g, device=dev)
+        tmp = torch.empty((len(mine), pd), dtype=slab.dtype, device=dev)
+        tmp_sc = torch.empty(len(mine), dtype=torch.float32, device=dev) if scales is not None else None
+        tmp_sh = torch.empty((len(mine), dim), dtype=torch.float32, device=dev)
+        nat.slab_append_f32(planted.contiguous(), tmp, 0, slab_type, scales=tmp_sc, shadow=tmp_sh)
+        slab[j] = tmp
+        shadow[j] = tmp_sh
+        if scales is not None:
+            scales[j] = tmp_sc
 
     class Ctx:
-        """Buffers of one in-flight query batch (a step touches nothing outside its Ctx + read-only state)."""
+        """Buffers of one in-flight query batch (a batch touches nothing outside its Ctx + read-only state)."""
         def __init__(self):
             self.q_out = torch.empty((qb, dim), dtype=torch.float32, device=dev)
             self.q16 = torch.empty((qb, pd), dtype=torch.float16, device=dev)
-            self.dummy16 = torch.empty((qb, pd), dtype=torch.float16, device=dev)
             self.enc_ws = torch.empty(enc.workspace_bytes(qb, QUERY_TOKENS), dtype=torch.uint8, device=dev)
-            self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k, rows), dtype=torch.uint8, device=dev)
-            self.out_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
-            self.out_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
+            self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k_scan, rows), dtype=torch.uint8, device=dev)
+            self.cand_s = torch.empty((nq_all, k_scan), dtype=torch.float32, device=dev)
+            self.cand_i = torch.empty((nq_all, k_scan), dtype=torch.int64, device=dev)
+            self.wire = nat.WireBlock(nq_all, k, dev, world)     # this rank's (ids | scores) block + the gathered blocks
             self.graphs = None
             if world > 1:
-                self.q_all = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
-                self.gs = torch.empty((world * nq_all, k), dtype=torch.float32, device=dev)
-                self.gi = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
                 self.fin_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
                 self.fin_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
+                if not strong:
+                    self.q_all32 = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
+                    self.q_all16 = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
 
-    # The step is three device segments with the two exchanges between them; every segment reads and
-    # writes fixed buffers of its Ctx, so each can be captured once into a hipGraph and replayed.
-    def seg_encode(c):      # token ids -> fp16 queries of this rank
+    # A batch = device segments with the collectives between them; every segment reads and writes fixed buffers
+    # of its Ctx, so each is captured once into a hipGraph and replayed.
+    def seg_encode(c):      # token ids -> fp32 embeddings + the scan's fp16 query block
         if args.scan_only:
-            nat.queries_to_f16(q32, slab_type, out=c.q16)
-        else:   # pooled embeddings leave the encoder as fp32 and as the scan's fp16 query block
+            c.q_out.copy_(q32)
+            nat.queries_to_f16(c.q_out, slab_type, out=c.q16)
+        else:
             enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=slab_type)
-        for _ in range(args.extra_launches):
-            nat.queries_to_f16(q32, slab_type, out=c.dummy16)
 
-    def seg_scan(c):        # all queries of the step x this rank's shard -> per-shard top-k
-        nat.cosine_topk(c.q_all if world > 1 else c.q16, slab, rows, dim, k, slab_type=slab_type, scales=scales,
-                        id_base=id_base, workspace=c.ws, out_scores=c.out_s, out_ids=c.out_i)
+    def seg_search(c, do_refine=refine):       # all queries of the batch x this rank's shard -> this rank's wire block
+        gathered_q = world > 1 and not strong
+        qa32 = c.q_all32 if gathered_q else c.q_out
+        if gathered_q:
+            nat.queries_to_f16(qa32, slab_type, out=c.q_all16)
+        qa16 = c.q_all16 if gathered_q else c.q16
+        if do_refine:
+            nat.cosine_topk(qa16, slab, rows, dim, k_scan, slab_type=slab_type, scales=scales, id_base=id_base,
+                            workspace=c.ws, out_scores=c.cand_s, out_ids=c.cand_i)
+            nat.refine_f32(qa32, shadow, rows, id_base, c.cand_i, k, out_scores=c.wire.scores, out_ids=c.wire.ids)
+        else:
+            nat.cosine_topk(qa16, slab, rows, dim, k, slab_type=slab_type, scales=scales, id_base=id_base,
+                            workspace=c.ws, out_scores=c.wire.scores, out_ids=c.wire.ids)
 
-    def seg_merge(c):       # N > 1: the gathered per-shard lists -> global top-k
-        nat.merge_topk(c.gs.view(world, nq_all, k), c.gi.view(world, nq_all, k), k, out_scores=c.fin_s, out_ids=c.fin_i)
+    def seg_merge(c):       # N > 1: the gathered wire blocks -> global top-k
+        nat.merge_topk_wire(c.wire.gathered, world, nq_all, k, k, out_scores=c.fin_s, out_ids=c.fin_i)
 
-    segs = (seg_encode, seg_scan) + ((seg_merge,) if world > 1 else ())
+    if world == 1:
+        segs = [lambda c: (seg_encode(c), seg_search(c))]
+        exchanges = []
+    elif strong:            # replicated queries: ONE collective per batch
+        segs = [lambda c: (seg_encode(c), seg_search(c)), seg_merge]
+        exchanges = [lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)]
+    else:
+        segs = [seg_encode, seg_search, seg_merge]
+        exchanges = [lambda c: dist.all_gather_into_tensor(c.q_all32, c.q_out),
+                     lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)]
 
-    def step(c):
-        run_seg = (lambda j: c.graphs[j].replay()) if c.graphs is not None else (lambda j: segs[j](c))
-        run_seg(0)
-        if world > 1:
-            dist.all_gather_into_tensor(c.q_all, c.q16)
-        run_seg(1)
-        if world > 1:
-            dist.all_gather_into_tensor(c.gs, c.out_s)
-            dist.all_gather_into_tensor(c.gi, c.out_i)
-            run_seg(2)
-            return c.fin_s, c.fin_i
-        return c.out_s, c.out_i
+    def batch(c):
+        for j, seg in enumerate(segs):
+            if c.graphs is not None:
+                c.graphs[j].replay()
+            else:
+                seg(c)
+            if j < len(exchanges):
+                exchanges[j](c)
+        return (c.fin_s, c.fin_i) if world > 1 else (c.wire.scores, c.wire.ids)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Throughput mode: S independent batches in flight, each on its own stream with its own buffers.  The
-    # device segments of a step (~45 small launches) are captured once per batch into hipGraphs and
-    # replayed; for N > 1 the RCCL collectives between the segments are launched eagerly (those of
-    # different batches are serialised on the process group's own stream; every rank issues them in the
-    # same order).
+    # Throughput mode: S independent batches in flight, each on its own stream with its own buffers.  For N > 1 the
+    # RCCL collective between the segments is launched eagerly (those of different batches are serialised on the
+    # process group's own stream; every rank issues them in the same order).
     n_streams = max(1, args.streams)
     use_graph = not args.no_graph
     ctxs = [Ctx() for _ in range(n_streams)]
@@ -209,8 +351,8 @@ def main():
     torch.cuda.synchronize()
     for c, st in zip(ctxs, streams):
         with torch.cuda.stream(st):
-            for _ in range(3):
-                step(c)
+            for _ in range(2):
+                batch(c)
         st.synchronize()
         if use_graph:
             # thread_local: with N > 1 the process group's watchdog thread polls events while we capture;
@@ -231,11 +373,11 @@ def main():
                 torch.cuda.synchronize()   # (no break: every rank must still run the same warm-up collectives)
     sync()
 
-    def run(n):
-        for it in range(n):
-            sidx = it % n_streams
-            with torch.cuda.stream(streams[sidx]):
-                step(ctxs[sidx])
+    def run(n_steps):
+        for _ in range(n_steps):
+            for c, st in zip(ctxs, streams):
+                with torch.cuda.stream(st):
+                    batch(c)
 
     run(args.warmup)
     sync()
@@ -243,49 +385,89 @@ def main():
     run(args.steps)
     sync()
     dt = time.perf_counter() - t0
-    res_i = ctxs[0].out_i
-    # functional check of the whole exchange (untimed): the final lists against a plain torch matmul + topk
-    # over every rank's shard, gathered and re-sorted -- catches any mix-up of query order, id bases,
-    # all-gather layout or merge
-    with torch.cuda.stream(streams[0]):
-        fin_s, fin_i = step(ctxs[0])
-    streams[0].synchronize()
-    q_chk = (ctxs[0].q16 if world == 1 else ctxs[0].q_all).float()[:, :dim]
-    ref_s = torch.full((nq_all, k), float("-inf"), device=dev)
-    ref_i = torch.full((nq_all, k), -1, dtype=torch.int64, device=dev)
-    for lo in range(0, rows, 250_000):
-        blk = slab[lo:lo + 250_000, :dim].float()
-        if scales is not None:
-            blk = blk * scales[lo:lo + 250_000, None]
-        sc_blk = q_chk @ blk.T
-        ts, ti = sc_blk.topk(min(k, sc_blk.shape[1]), dim=1)
-        cat_s, cat_i = torch.cat([ref_s, ts], 1), torch.cat([ref_i, ti + lo + id_base], 1)
-        ref_s, pos = cat_s.topk(k, dim=1)
-        ref_i = torch.gather(cat_i, 1, pos)
-    if world > 1:
-        all_s = torch.empty((world * nq_all, k), device=dev); all_i = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(all_s, ref_s.contiguous()); dist.all_gather_into_tensor(all_i, ref_i.contiguous())
-        all_s = all_s.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)
-        all_i = all_i.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)
-        ref_s, pos = all_s.topk(k, dim=1)
-        ref_i = torch.gather(all_i, 1, pos)
-    tol = 2e-3 if slab_type == nat.SLAB_I8 else 2e-5     # int8: the kernel searches with 16-bit fixed-point queries
-    score_err = float((fin_s - ref_s).abs().max().item())
-    id_match = float((fin_i == ref_i).float().mean().item())
-    exchange_ok = bool(score_err < tol and id_match > 0.98)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    q_per_step = nq_all * n_streams
     ms_step = dt / args.steps * 1e3
-    qps = nq_all * args.steps / dt
+    qps = q_per_step * args.steps / dt
 
-    # ---- roofline of the dominant kernel (the scan), hipEvent-timed on the launch stream
-    q16_all = nat.queries_to_f16(q32, slab_type) if world == 1 else ctxs[0].q_all
-    ms_total, ms_scan = nat.time_cosine_topk(q16_all, slab, rows, dim, k, max(20, min(args.steps, 200)),
+    # ---- correctness of the timed path (untimed): its final lists against the exact ranking of the UNQUANTISED
+    # fp32 rows of every shard (fp64 accumulation) -- catches quantisation loss as well as any mix-up of query
+    # order, id bases, wire layout or merge.
+    def gathered_queries():
+        if world > 1 and not strong:
+            qa = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(qa, ctxs[0].q_out.contiguous())
+            return qa
+        return ctxs[0].q_out
+
+    with torch.cuda.stream(streams[0]):
+        fin_s, fin_i = batch(ctxs[0])
+        fin_s, fin_i = fin_s.clone(), fin_i.clone()
+    streams[0].synchronize()
+    q_truth = gathered_queries()
+    gt_s, gt_i = exact_topk_f64(torch, q_truth, shadow, rows, k, id_base)
+    if world > 1:
+        all_s = torch.empty((world * nq_all, k), dtype=torch.float64, device=dev)
+        all_i = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_s, gt_s.contiguous()); dist.all_gather_into_tensor(all_i, gt_i.contiguous())
+        all_s = all_s.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)
+        all_i = all_i.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)   # rank-major = id-ascending
+        o = torch.argsort(all_s, dim=1, descending=True, stable=True)[:, :k]
+        gt_s, gt_i = torch.gather(all_s, 1, o), torch.gather(all_i, 1, o)
+    rec_timed = recall_rows(fin_i, gt_i)
+    recall_timed = float(rec_timed.mean().item())
+    ids_identical = float((fin_i == gt_i).all(dim=1).float().mean().item())
+    score_err = float((fin_s.double() - gt_s).abs().max().item())
+    # the other mode, for the record (one untimed eager batch): plain fp16/int8 scan with k' = k, or the refined one
+    c0 = ctxs[0]
+    with torch.cuda.stream(streams[0]):
+        seg_encode(c0)
+        if world > 1 and not strong:
+            dist.all_gather_into_tensor(c0.q_all32, c0.q_out)
+        if refine:
+            seg_search(c0, do_refine=False)
+        else:
+            c0.cand_s = torch.empty((nq_all, max(k, K_SCAN)), dtype=torch.float32, device=dev)
+            c0.cand_i = torch.empty((nq_all, max(k, K_SCAN)), dtype=torch.int64, device=dev)
+            c0.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, max(k, K_SCAN), rows), dtype=torch.uint8, device=dev)
+            qa16 = c0.q_all16 if (world > 1 and not strong) else c0.q16
+            qa32 = c0.q_all32 if (world > 1 and not strong) else c0.q_out
+            nat.cosine_topk(qa16, slab, rows, dim, max(k, K_SCAN), slab_type=slab_type, scales=scales, id_base=id_base,
+                            workspace=c0.ws, out_scores=c0.cand_s, out_ids=c0.cand_i)
+            nat.refine_f32(qa32, shadow, rows, id_base, c0.cand_i, k, out_scores=c0.wire.scores, out_ids=c0.wire.ids)
+        if world > 1:
+            dist.all_gather_into_tensor(c0.wire.gathered, c0.wire.buf)
+            seg_merge(c0)
+        oth_s, oth_i = ((c0.fin_s, c0.fin_i) if world > 1 else (c0.wire.scores, c0.wire.ids))
+    streams[0].synchronize()
+    recall_other = float(recall_rows(oth_i, gt_i).mean().item())
+    err_other = float((oth_s.double() - gt_s).abs().max().item())
+    tol = 1e-5 if refine else (5e-3 if slab_type == nat.SLAB_I8 else 1e-3)
+    check_ok = bool(score_err < tol and recall_timed >= (0.999 if refine else 0.8))
+    recall_report = {"timed_path": round(recall_timed, 5),
+                     "timed_mode": (f"{slab_kind} scan k'={k_scan} + fp32 shadow re-rank" if refine else f"{slab_kind} scan only"),
+                     "queries_with_identical_ordered_ids": round(ids_identical, 5), "max_abs_score_err_vs_fp64": score_err,
+                     ("scan_only_no_refine" if refine else "with_fp32_refine"): round(recall_other, 5),
+                     ("scan_only_max_abs_score_err" if refine else "with_fp32_refine_max_abs_score_err"): err_other}
+
+    # ---- roofline of the dominant kernel (the scan), hipEvent-timed on the launch stream; the re-rank beside it
+    qa16 = ctxs[0].q_all16 if (world > 1 and not strong) else ctxs[0].q16
+    ms_total, ms_scan = nat.time_cosine_topk(qa16, slab, rows, dim, k_scan, max(10, min(args.steps, 50)),
                                              slab_type=slab_type, scales=scales)
+    ms_refine = None
+    if refine:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        qa32 = ctxs[0].q_all32 if (world > 1 and not strong) else ctxs[0].q_out
+        e0.record()
+        for _ in range(50):
+            nat.refine_f32(qa32, shadow, rows, id_base, ctxs[0].cand_i, k, out_scores=ctxs[0].wire.scores, out_ids=ctxs[0].wire.ids)
+        e1.record(); e1.synchronize()
+        ms_refine = e0.elapsed_time(e1) / 50
     elem = 1 if slab_type == nat.SLAB_I8 else 2
-    alg_bytes = rows * pd * elem + (rows * 4 if slab_type == nat.SLAB_I8 else 0) + nq_all * pd * 2 + nq_all * k * 8
+    alg_bytes = rows * pd * elem + (rows * 4 if slab_type == nat.SLAB_I8 else 0) + nq_all * pd * 2 + nq_all * k_scan * 8
     achieved = alg_bytes / (ms_scan * 1e-3) / 1e9
     # HBM traffic per launch comes from the committed PMC passes of this same command (bench.py cannot
     # read hardware counters itself); null when that workload has not been profiled yet
@@ -295,18 +477,17 @@ def main():
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
             with open(path) as fh:
                 pm = json.load(fh)
-            if args.workload in pm and world == 1:
-                traffic = pm[args.workload]["hbm_read_bytes_per_launch"]
+            key = f"{args.workload}-n{world}" if f"{args.workload}-n{world}" in pm else None
+            if key and pm[key].get("rows") == rows:
+                traffic = pm[key]["hbm_read_bytes_per_launch"]
                 traffic_src = os.path.relpath(path, ROOT)
                 break
     except Exception:
         pass
     # Which roof bounds the launch: flop per algorithmic byte (= queries per launch for fp16, 2x that for int8)
     # against the ridge of the dense MFMA peak over the HBM peak (MI355X_MICROARCH.md: 2.5 PF fp16 / 5 PF int8, 8 TB/s).
-    # One rank of an N-GPU step scans its shard for the queries of ALL ranks, so from ~313 queries on the scan is
-    # matrix-bound and is priced against the MFMA peak; both fractions are reported either way.
     alg_flops = 2.0 * nq_all * rows * pd
-    mfma_peak_tf = 5000.0 if slab_type == nat.SLAB_I8 else 2500.0
+    mfma_peak_tf = MFMA_PEAK_TF[slab_kind]
     achieved_tf = alg_flops / (ms_scan * 1e-3) / 1e12
     hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, achieved_tf / mfma_peak_tf
     mfma_bound = (alg_flops / alg_bytes) > (mfma_peak_tf * 1e12) / (HBM_PEAK_GBS * 1e9)
@@ -314,69 +495,76 @@ def main():
                 "achieved": round(achieved_tf if mfma_bound else achieved, 1),
                 "peak": mfma_peak_tf if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round(mfma_frac if mfma_bound else hbm_frac, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": nat.scan_plan_describe(nq_all, dim, k, rows, slab_type),
-                "kernel_ms": round(ms_scan, 5), "scan_plus_merge_ms": round(ms_total, 5),
+                "kernel": nat.scan_plan_describe(nq_all, dim, k_scan, rows, slab_type),
+                "kernel_ms": round(ms_scan, 5), "scan_merge_refine_ms": round(ms_total, 5),
+                "fp32_rerank_ms": round(ms_refine, 5) if ms_refine is not None else None,
+                "fp32_shadow_bytes": int(rows * dim * 4) if refine else 0,
                 "algorithmic_bytes": int(alg_bytes), "algorithmic_flops": int(alg_flops),
                 "hbm_frac": round(hbm_frac, 4), "mfma_frac": round(mfma_frac, 4)}
 
-    # ---- correctness of the timed result + CPU baseline (rank 0, N=1 only): the oracle, same workload
+    # ---- CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same workload
     cpu = None
-    recall = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import encoder_ref as er, scan_ref   # the CPU restatement: only ever the baseline / checker
         cfg = er.EncoderConfig(shape.vocab_size, shape.hidden, shape.layers, shape.heads, shape.ffn, shape.max_pos, 2,
                                shape.ln_eps, shape.max_seq, shape.pooling)
         sample_rows = min(rows, 200_000)
-        slab_h = slab[:sample_rows, :dim].cpu().numpy()
-        sc_h = scales[:sample_rows].cpu().numpy() if scales is not None else None
-        q_h = nat.queries_to_f16(q32, slab_type)[:, :dim].cpu().numpy()
-        # check the GPU's answer on the sample prefix against the oracle (exactness of the timed path)
-        gs_, gi_ = nat.cosine_topk(nat.queries_to_f16(q32, slab_type), slab, sample_rows, dim, k, slab_type=slab_type,
-                                   scales=scales)
-        rs, ri = scan_ref.cosine_topk_ref(q_h, slab_h, k, scales=sc_h)
+        rows_h = shadow[:sample_rows].cpu().numpy()          # the reference stores fp32 (rag/indexing.py:114-119)
+        q_h = q32.cpu().numpy()
+        # the HIP path on the same sample prefix against the oracle (exactness of the kernels themselves)
+        cs_, ci_ = nat.cosine_topk(ctxs[0].q16, slab, sample_rows, dim, k_scan, slab_type=slab_type, scales=scales)
+        gs_, gi_ = nat.refine_f32(q32, shadow, sample_rows, 0, ci_, k)
+        rs, ri = scan_ref.cosine_topk_ref(q_h, rows_h, k)
         gi_h = gi_.cpu().numpy()
-        recall = float(np.mean([scan_ref.recall_at_k(gi_h[r], ri[r]) for r in range(qb)]))
+        recall_oracle = float(np.mean([scan_ref.recall_at_k(gi_h[r], ri[r]) for r in range(qb)]))
         max_err = float(np.abs(gs_.cpu().numpy() - rs).max())
-        # time the oracle on the bounded sample: encoder (fp32 torch CPU restatement) + exact scan
         n_done, t_enc, t_scan = 0, 0.0, 0.0
-        t_start = time.perf_counter()
         while (t_enc + t_scan) < args.cpu_seconds:
             ta = time.perf_counter()
             er.encode_ref(ids_h, mask_h, enc_w, cfg)
             tb = time.perf_counter()
-            scan_ref.cosine_topk_ref(q_h, slab_h, k, scales=sc_h)
+            scan_ref.cosine_topk_ref(q_h, rows_h, k)
             tc = time.perf_counter()
             t_enc += tb - ta; t_scan += tc - tb
             n_done += 1
         t_cpu = t_enc + t_scan
-        # queries/s over the FULL shard: the scan part of the sample's time scales by rows/sample_rows
+        # queries/s over the FULL corpus: the scan part of the sample's time scales by rows/sample_rows
         cpu_qps = qb * n_done / (t_enc + t_scan * (rows / sample_rows))
-        cpu = {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": int(torch.get_num_threads()),
-               "kind": "port",
+        cpu = {"value": round(cpu_qps, 2), "unit": "queries/s", "cores": int(torch.get_num_threads()),
+               "cpu_model": cpu_model(), "kind": "port",
                "sample": f"oracle encoder_ref.encode_ref ({qb}x{QUERY_TOKENS} tokens, torch fp32) + scan_ref.cosine_topk_ref "
-                         f"(numpy sgemm + exact top-k) over {sample_rows} of {rows} rows; {n_done} passes in "
-                         f"{t_cpu:.1f}s (encoder {t_enc:.1f}s, scan {t_scan:.1f}s), scan time scaled by rows",
-               "recall_at_10_gpu_vs_oracle": recall, "max_abs_score_err": max_err}
+                         f"(numpy fp32 sgemm + exact top-k over the fp32 rows) on {sample_rows} of {rows} rows; {n_done} passes in "
+                         f"{t_cpu:.1f}s (encoder {t_enc:.1f}s, scan {t_scan:.1f}s), scan time scaled by rows/sample",
+               "recall_at_10_gpu_vs_oracle_on_sample": recall_oracle, "max_abs_score_err_on_sample": max_err}
 
     if rank == 0:
         line = {
-            "metric": "queries/sec over N-vector corpus (exact cosine top-k, Recall@10 vs oracle)",
+            "metric": "queries/sec over N-vector corpus (exact cosine top-k; Recall@10 vs the exact fp32 ranking)",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 x f16 -> f32" if slab_type == nat.SLAB_F16 else "i8(f16) x f16 -> f32",
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f16 x f16 -> f32" if slab_type == nat.SLAB_F16 else "i8 x i16(f16 query) -> i32 -> f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "rows_per_gpu": rows, "corpus_rows": rows * world, "dim": dim,
-                       "queries_per_rank_per_step": qb, "queries_per_step": nq_all, "top_k": k,
-                       "slab": slab_kind, "encoder_in_step": not args.scan_only,
+            "config": {"workload": args.workload, "corpus_rows": corpus_rows, "rows_per_gpu": rows, "dim": dim,
+                       "queries_per_batch": nq_all, "batches_per_step": n_streams, "queries_per_step": q_per_step,
+                       "ms_per_batch": round(ms_step / n_streams, 5), "top_k": k, "k_scan": k_scan,
+                       "slab": slab_kind, "refine_fp32": refine, "encoder_in_step": not args.scan_only,
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
-                       "query_tokens": QUERY_TOKENS, "streams_in_flight": n_streams, "hip_graph": use_graph, "exchange_check": {"ok": exchange_ok, "max_score_err": score_err, "id_match": round(id_match, 4)},
+                       "query_tokens": QUERY_TOKENS, "hip_graph": use_graph,
+                       "collectives_per_batch": len(exchanges),
+                       "recall_at_10_vs_fp32": recall_report, "check_ok": check_ok,
                        "index_build_s_per_gpu": round(t_build, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        ok_t = torch.tensor([1 if check_ok else 0], device=dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        check_ok = bool(ok_t.item())
         dist.destroy_process_group()
+    if not check_ok:
+        print(f"[bench] rank {rank}: result check FAILED (recall {recall_timed}, max score err {score_err})", file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

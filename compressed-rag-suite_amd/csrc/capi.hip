@@ -137,7 +137,7 @@ int set_error(int code, const char* msg) {  // shared with enc_capi.hip
 extern "C" {
 
 const char* crs_last_error(void) { return g_err; }
-int crs_abi_version(void) { return 1; }
+int crs_abi_version(void) { return 2; }
 int crs_row_elems(int dim, int slab_type) {
   if (dim <= 0) return 0;
   const int g = slab_type == CRS_SLAB_I8 ? 256 : 128;
@@ -287,6 +287,31 @@ int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_d
   const int e = crs::rescore_launch(q32_dev, nq, dim, shadow_dev, n_rows, id_base, k, scores_dev,
                                     ids_dev, (hipStream_t)stream);
   return e ? hip_fail((hipError_t)e, "rescore launch") : CRS_OK;
+}
+
+int crs_refine_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
+                   int64_t id_base, const int64_t* cand_ids_dev, int k_in, int k_out,
+                   float* out_scores_dev, int64_t* out_ids_dev, void* stream) {
+  if (nq <= 0 || dim <= 0 || n_rows <= 0 || k_out <= 0 || k_in < k_out || k_in > CRS_MAX_K)
+    return fail(CRS_EINVAL, "bad sizes (1 <= k_out <= k_in <= CRS_MAX_K)");
+  if (!q32_dev || !shadow_dev || !cand_ids_dev || !out_scores_dev || !out_ids_dev) return fail(CRS_EINVAL, "null pointer");
+  const int e = crs::refine_f32_launch(q32_dev, nq, dim, shadow_dev, n_rows, id_base, cand_ids_dev, k_in, k_out,
+                                       out_scores_dev, out_ids_dev, (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "refine_f32 launch") : CRS_OK;
+}
+
+size_t crs_wire_scores_offset(int nq, int k) { return (nq > 0 && k > 0) ? (size_t)nq * k * 8 : 0; }
+size_t crs_wire_bytes(int nq, int k) {
+  return (nq > 0 && k > 0) ? (size_t)nq * k * 8 + align_up((size_t)nq * k * 4, 8) : 0;
+}
+int crs_merge_topk_wire(const void* wire_dev, int nlists, int nq, int k_in, int k_out,
+                        float* out_scores_dev, int64_t* out_ids_dev, void* stream) {
+  if (nlists <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0 || k_out > CRS_MAX_K) return fail(CRS_EINVAL, "bad sizes (k_out <= CRS_MAX_K)");
+  if (!wire_dev || !out_scores_dev || !out_ids_dev) return fail(CRS_EINVAL, "null pointer");
+  if ((uintptr_t)wire_dev & 7) return fail(CRS_EINVAL, "wire buffer must be 8-byte aligned");
+  const int e = crs::merge_launch_wire(wire_dev, crs_wire_bytes(nq, k_in), crs_wire_scores_offset(nq, k_in), nlists, nq,
+                                       k_in, k_out, out_scores_dev, out_ids_dev, (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "merge launch") : CRS_OK;
 }
 
 int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type, char* buf, size_t cap) {

@@ -122,7 +122,59 @@ __global__ __launch_bounds__(64) void sort_rows_kernel(int nq, int k, float* __r
   }
 }
 
+// Over-fetch re-rank (crs_refine_f32): one 256-thread workgroup per query.  Wave w re-scores candidates
+// w, w+4, ... (fp32 FMA over the lane's strided elements, butterfly sum), the scores meet in LDS, and the
+// first k_in threads rank themselves by counting (score desc, id asc, empties last); ranks < k_out leave.
+__global__ __launch_bounds__(256) void refine_f32_kernel(const float* __restrict__ q32, int dim,
+                                                        const float* __restrict__ shadow, int64_t n_rows,
+                                                        int64_t id_base, const int64_t* __restrict__ cand,
+                                                        int k_in, int k_out, float* __restrict__ out_s,
+                                                        int64_t* __restrict__ out_i) {
+  __shared__ float sh_s[64];
+  __shared__ int64_t sh_i[64];
+  const int qi = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* a = q32 + (size_t)qi * dim;
+  for (int c = wave; c < k_in; c += 4) {
+    int64_t id = cand[(size_t)qi * k_in + c];
+    const int64_t row = id - id_base;
+    const bool ok = id >= 0 && row >= 0 && row < n_rows;
+    float acc = 0.f;
+    if (ok) {
+      const float* b = shadow + (size_t)row * dim;
+      for (int e = lane; e < dim; e += 64) acc = fmaf(a[e], b[e], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) { sh_s[c] = ok ? acc : kNegInf; sh_i[c] = ok ? id : (int64_t)-1; }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < k_out) { out_s[(size_t)qi * k_out + t] = kNegInf; out_i[(size_t)qi * k_out + t] = -1; }
+  __syncthreads();
+  if (t < k_in) {
+    const float s = sh_s[t];
+    const int64_t id = sh_i[t];
+    if (id >= 0) {
+      int rank = 0;
+      for (int j = 0; j < k_in; ++j) {
+        const float sj = sh_s[j];
+        const int64_t ij = sh_i[j];
+        rank += (ij >= 0 && (sj > s || (sj == s && (ij < id || (ij == id && j < t))))) ? 1 : 0;
+      }
+      if (rank < k_out) { out_s[(size_t)qi * k_out + rank] = s; out_i[(size_t)qi * k_out + rank] = id; }
+    }
+  }
+}
+
 }  // namespace
+
+int refine_f32_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows, int64_t id_base,
+                      const int64_t* cand, int k_in, int k_out, float* out_s, int64_t* out_i, hipStream_t stream) {
+  if (nq <= 0) return 0;
+  hipLaunchKernelGGL(refine_f32_kernel, dim3(nq), dim3(256), 0, stream, q32, dim, shadow, n_rows, id_base, cand,
+                     k_in, k_out, out_s, out_i);
+  return (int)hipGetLastError();
+}
 
 int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_type, void* slab,
                        float* scales, float* shadow, int64_t row0, hipStream_t stream) {

@@ -59,7 +59,7 @@ template <typename IdT>
 __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict__ scores,
                                                         const IdT* __restrict__ ids, int nlists,
                                                         int k_in, int k_out, size_t list_stride,
-                                                        size_t q_stride, int64_t id_base,
+                                                        size_t id_list_stride, size_t q_stride, int64_t id_base,
                                                         float* __restrict__ out_s,
                                                         int64_t* __restrict__ out_i) {
   __shared__ float sh_sorted[4][64];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   // time with all loads issued before any use, so L2 latency is paid once per batch of 8.
   const float* qs = scores + (size_t)q * q_stride;
   const IdT* qi = ids + (size_t)q * q_stride;
-  const bool contig = (list_stride == (size_t)k_in);
+  const bool contig = (list_stride == (size_t)k_in) && (id_list_stride == (size_t)k_in);
 #define CRS_FOR_EACH_ENTRY(BODY)                                                         \
   for (int e0 = tid; e0 < m; e0 += 8 * kThreads) {                                       \
     float s_[8];                                                                         \
@@ -85,10 +85,13 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
       const int e = e0 + u * kThreads;                                                   \
       const bool in = e < m;                                                             \
-      size_t at = 0;                                                                     \
-      if (in) at = contig ? (size_t)e : (size_t)(e / k_in) * list_stride + (e % k_in);   \
+      size_t at = 0, ati = 0;                                                            \
+      if (in) {                                                                          \
+        at = contig ? (size_t)e : (size_t)(e / k_in) * list_stride + (e % k_in);         \
+        ati = contig ? (size_t)e : (size_t)(e / k_in) * id_list_stride + (e % k_in);     \
+      }                                                                                  \
       s_[u] = qs[at];                                                                    \
-      id_[u] = in ? qi[at] : (IdT)-1;                                                    \
+      id_[u] = in ? qi[ati] : (IdT)-1;                                                   \
     }                                                                                    \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
       const float s = s_[u];                                                             \
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
 int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,
                      int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream) {
   hipLaunchKernelGGL((merge_kernel<int>), dim3(nq), dim3(kThreads), 0, stream, scores, rows, nlists,
-                     k_in, k_out, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids);
+                     k_in, k_out, (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids);
   return (int)hipGetLastError();
 }
 
@@ -219,8 +222,18 @@ int merge_launch_i64(const float* scores, const int64_t* ids, int nlists, int nq
                      int k_out, float* out_scores, int64_t* out_ids, hipStream_t stream) {
   // all-gather layout: [nlists, nq, k_in]
   hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, scores, ids,
-                     nlists, k_in, k_out, (size_t)nq * k_in, (size_t)k_in, (int64_t)0, out_scores,
+                     nlists, k_in, k_out, (size_t)nq * k_in, (size_t)nq * k_in, (size_t)k_in, (int64_t)0, out_scores,
                      out_ids);
+  return (int)hipGetLastError();
+}
+
+// wire layout (crs_hip.h): nlists blocks of `block_bytes`, each [ids int64 [nq, k_in] | scores fp32 [nq, k_in] | pad]
+int merge_launch_wire(const void* wire, size_t block_bytes, size_t scores_off, int nlists, int nq, int k_in, int k_out,
+                      float* out_scores, int64_t* out_ids, hipStream_t stream) {
+  const int64_t* ids = reinterpret_cast<const int64_t*>(wire);
+  const float* scores = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wire) + scores_off);
+  hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, scores, ids, nlists, k_in, k_out,
+                     block_bytes / 4, block_bytes / 8, (size_t)k_in, (int64_t)0, out_scores, out_ids);
   return (int)hipGetLastError();
 }
 

@@ -60,7 +60,12 @@ int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, i
 int merge_launch_i64(const float* scores, const int64_t* ids, int nlists, int nq, int k_in, int k_out,
                      float* out_scores, int64_t* out_ids, hipStream_t stream);
 
+int merge_launch_wire(const void* wire, size_t block_bytes, size_t scores_off, int nlists, int nq, int k_in, int k_out,
+                      float* out_scores, int64_t* out_ids, hipStream_t stream);
+
 // convert.hip
+int refine_f32_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows, int64_t id_base,
+                      const int64_t* cand, int k_in, int k_out, float* out_s, int64_t* out_i, hipStream_t stream);
 int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_type, void* slab,
                        float* scales, float* shadow, int64_t row0, hipStream_t stream);
 int queries_to_f16_launch(const float* q, int nq, int dim, int pdim, _Float16* out, hipStream_t stream);

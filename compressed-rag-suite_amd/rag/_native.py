@@ -33,6 +33,11 @@ _SIGNATURES = {
                                c_void_p]),
     "crs_rescore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                 c_void_p, c_void_p]),
+    "crs_refine_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int,
+                               c_void_p, c_void_p, c_void_p]),
+    "crs_wire_bytes": (c_size_t, [c_int, c_int]),
+    "crs_wire_scores_offset": (c_size_t, [c_int, c_int]),
+    "crs_merge_topk_wire": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "crs_scan_plan_describe": (c_int, [c_int, c_int, c_int, c_int64, c_int, ctypes.c_char_p, c_size_t]),
     "crs_time_cosine_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
                                      c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
@@ -161,6 +166,47 @@ def rescore_f32(q32, shadow, n_rows: int, id_base: int, scores, ids) -> None:
     k = scores.shape[1]
     check(load().crs_rescore_f32(_ptr(q32), nq, dim, _ptr(shadow), n_rows, id_base, k, _ptr(scores),
                                  _ptr(ids), _stream_ptr()))
+
+
+def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out_scores=None, out_ids=None):
+    """Exact fp32 re-rank of over-fetched candidates: cand_ids int64 [nq, k_in] (what cosine_topk found in the
+    fp16/int8 slab) -> the k_out best by <q32, shadow[id - id_base]> (score desc, id asc)."""
+    import torch
+    nq, dim = q32.shape
+    k_in = cand_ids.shape[1]
+    if out_scores is None:
+        out_scores = torch.empty((nq, k_out), dtype=torch.float32, device=q32.device)
+    if out_ids is None:
+        out_ids = torch.empty((nq, k_out), dtype=torch.int64, device=q32.device)
+    check(load().crs_refine_f32(_ptr(q32), nq, dim, _ptr(shadow), n_rows, id_base, _ptr(cand_ids), k_in, k_out,
+                                _ptr(out_scores), _ptr(out_ids), _stream_ptr()))
+    return out_scores, out_ids
+
+
+class WireBlock:
+    """One rank's per-shard result in the one-collective wire layout of include/crs_hip.h:
+    [ids int64 [nq, k] | scores fp32 [nq, k] | pad].  `.ids` / `.scores` are views into `.buf`, so the
+    search kernels write the block in place and `buf` is what the all-gather sends."""
+
+    def __init__(self, nq: int, k: int, device, world: int = 1):
+        import torch
+        lib = load()
+        self.nq, self.k, self.world = nq, k, world
+        self.nbytes = int(lib.crs_wire_bytes(nq, k))
+        off = int(lib.crs_wire_scores_offset(nq, k))
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.ids = self.buf[:off].view(torch.int64).view(nq, k)
+        self.scores = self.buf[off:off + nq * k * 4].view(torch.float32).view(nq, k)
+        self.gathered = torch.zeros(world * self.nbytes, dtype=torch.uint8, device=device) if world > 1 else None
+
+
+def merge_topk_wire(gathered, nlists: int, nq: int, k_in: int, k_out: int, out_scores=None, out_ids=None):
+    """gathered: cuda uint8 [nlists * crs_wire_bytes(nq, k_in)] (the all-gathered WireBlocks) -> global top-k_out."""
+    import torch
+    out_s = out_scores if out_scores is not None else torch.empty((nq, k_out), dtype=torch.float32, device=gathered.device)
+    out_i = out_ids if out_ids is not None else torch.empty((nq, k_out), dtype=torch.int64, device=gathered.device)
+    check(load().crs_merge_topk_wire(_ptr(gathered), nlists, nq, k_in, k_out, _ptr(out_s), _ptr(out_i), _stream_ptr()))
+    return out_s, out_i
 
 
 def scan_plan_describe(nq: int, dim: int, k: int, n_rows: int, slab_type: int = SLAB_F16) -> str:

@@ -83,6 +83,27 @@ int crs_merge_topk(const float* scores_dev, const int64_t* ids_dev, int nlists, 
 int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
                     int64_t id_base, int k, float* scores_dev, int64_t* ids_dev, void* stream);
 
+/* Over-fetch + exact re-rank in one launch (Recall@10 = 1.0 against the fp32 ranking the
+ * reference's ChromaDB collection keeps, rag/indexing.py:114-119).  cand_ids [nq, k_in] are the rows a
+ * crs_cosine_topk call with k = k_in >= k_out found in the fp16 / int8 slab; each is re-scored as the fp32
+ * dot product <q32[i], shadow[id - id_base]>, the k_in candidates are ranked (score desc, id asc; ids < 0
+ * or outside this shard are empty) and the best k_out leave as out_scores fp32 [nq, k_out] / out_ids int64
+ * [nq, k_out] (empty slots: -inf, -1).  One workgroup per query; k_out <= k_in <= CRS_MAX_K. */
+int crs_refine_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
+                   int64_t id_base, const int64_t* cand_ids_dev, int k_in, int k_out,
+                   float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* ---- one-collective exchange (ONE all-gather per query batch) ------------------
+ * A rank's per-shard result travels as one contiguous "wire block":
+ *     [ ids int64 [nq, k] | scores fp32 [nq, k] | pad to 8 bytes ]        crs_wire_bytes(nq, k) bytes
+ * crs_cosine_topk / crs_refine_f32 write it in place (out_ids = block, out_scores = block +
+ * crs_wire_scores_offset(nq, k)); an all-gather of the blocks gives [nlists][crs_wire_bytes] and
+ * crs_merge_topk_wire ranks it like crs_merge_topk. */
+size_t crs_wire_bytes(int nq, int k);
+size_t crs_wire_scores_offset(int nq, int k);
+int crs_merge_topk_wire(const void* wire_dev, int nlists, int nq, int k_in, int k_out,
+                        float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
 /* Which scan kernel (and launch geometry) crs_cosine_topk would use for these sizes on the current
  * device, as text, e.g. "scan_tb_kernel<384,32,4,0> streams=768 qblocks=1 kp=5 + merge + refine".
  * For bench.py / profiles only; writes at most `cap` bytes including the terminator. */

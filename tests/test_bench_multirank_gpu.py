@@ -1,8 +1,10 @@
 """bench.py's N > 1 step on the one-GPU box: two ranks sharing the card, gloo for the collectives (RCCL needs one
-GPU per rank).  Everything else is the real path -- graph-captured device segments, the all-gather of the fp16
-queries, every rank scanning its shard for the queries of both ranks (the wide scan kernel), the all-gather of
-the per-shard lists and the final merge -- and bench.py itself checks the exchanged result against a torch brute
-force over both shards (config.exchange_check)."""
+GPU per rank).  Everything else is the real path -- graph-captured device segments, every rank scanning its row
+shard (over-fetch k' = 16), the fp32 shadow re-rank written straight into the rank's wire block, ONE all-gather
+of the wire blocks and the final merge -- and bench.py itself checks the exchanged result against the exact
+fp64 ranking of the unquantised rows of both shards (config.recall_at_10_vs_fp32, config.check_ok; it exits
+non-zero when that check fails).  Strong scaling (the default: fixed corpus split over the ranks, replicated
+64-query batch, one collective per batch) and weak scaling (queries all-gathered first: the wide scan kernel)."""
 import json
 import os
 import subprocess
@@ -14,18 +16,41 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_step_exchange_is_exact(cuda):
+def _run(extra, port):
     env = dict(os.environ, CRS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "6", "--warmup", "2", "--streams", "3", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "1", "--streams", "3", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["queries_per_step"] == 128 and d["config"]["corpus_rows"] == 200_000
-    chk = d["config"]["exchange_check"]
-    assert chk["ok"] and chk["id_match"] > 0.999 and chk["max_score_err"] < 2e-5
-    assert d["config"]["hip_graph"] is True
+    return json.loads(lines[0])
+
+
+def test_two_rank_strong_step_is_exact_vs_fp32(cuda):
+    d = _run(["--workload", "c4", "--rows", "600000"], 29533)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert c["corpus_rows"] == 600_000 and c["rows_per_gpu"] == 300_000 and c["queries_per_batch"] == 64
+    assert c["queries_per_step"] == 64 * 3 and c["collectives_per_batch"] == 1
+    assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
+    assert c["recall_at_10_vs_fp32"]["max_abs_score_err_vs_fp64"] < 1e-5
+    assert c["hip_graph"] is True and c["refine_fp32"] is True
+    assert "scan_tb_kernel" in d["roofline"]["kernel"]
+
+
+def test_two_rank_weak_step_is_exact_vs_fp32(cuda):
+    d = _run(["--workload", "c2", "--scaling", "weak"], 29534)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert c["corpus_rows"] == 200_000 and c["queries_per_batch"] == 128 and c["collectives_per_batch"] == 2
+    assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
     assert "scan_wide_kernel" in d["roofline"]["kernel"]
+
+
+def test_int8_two_rank_strong_recall_is_one_after_refine(cuda):
+    d = _run(["--workload", "c5", "--rows", "400000"], 29535)
+    c = d["config"]
+    assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
+    assert c["recall_at_10_vs_fp32"]["scan_only_no_refine"] < 1.0      # int8 alone does flip ranks: the refine is what fixes it

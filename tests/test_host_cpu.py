@@ -105,7 +105,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert declared == set(nat.exported_symbols()), "binding table and headers disagree"
-    assert lib.crs_abi_version() == 1
+    assert lib.crs_abi_version() == 2
     assert [lib.crs_padded_dim(d) for d in (1, 100, 128, 384, 768, 1000)] == [128, 128, 128, 384, 768, 1024]
 
 
