@@ -211,9 +211,10 @@ struct WaveState {
 };
 
 // ---- variant A: register-staged double buffer, 2 workgroups per CU.
-// ASM_LOADS: issue the next tile's global loads through inline asm right at the top of the
-// iteration (hipcc otherwise sinks plain loads down to the ds_write that consumes them, which
-// serialises HBM latency with the math), and retire them with one hand-placed vmcnt(0).
+// ASM_LOADS (name kept from round 1; there is no inline-asm register load left anywhere in the library): this
+// instantiation also polls the shared threshold.  All global loads are compiler-visible -- an asm load whose
+// destination the compiler could copy or spill before the counted wait produced one wrong answer in round 1.
+// These threshold kernels now only serve 16 < k <= 64 on long streams; everything else runs the tile-best kernels.
 // BOOT: peel the first two tiles of the stream and bootstrap the threshold from them in registers.
 // A separate instantiation (not a runtime flag): with the peeled code present hipcc schedules the
 // steady-state loop ~10 % slower (C4 177 -> 200 us), while short streams (C2, 6 tiles per workgroup)
@@ -256,13 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
         const unsigned off = (unsigned)(j * kThreads + tid) * 16u;
-        if (ASM_LOADS) {
-          u32x4 x;
-          asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-          st[j] = x;
-        } else {
-          st[j] = *reinterpret_cast<const u32x4*>(base + off);
-        }
+        st[j] = *reinterpret_cast<const u32x4*>(base + off);   // compiler-visible: it places the waits itself
       }
     } else {  // ragged last tile, or past the end: clamp every lane to the slab's last 16 bytes
 #pragma unroll
@@ -270,34 +265,17 @@ __global__ __launch_bounds__(kThreads, 2) void scan_f16_kernel(const ScanArgs a)
         size_t off = (size_t)tile * C::kTileBytes + (size_t)(j * kThreads + tid) * 16;
         off = off > last_chunk ? last_chunk : off;
         const char* p = slab + off;
-        if (ASM_LOADS) {
-          u32x4 x;
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-          st[j] = x;
-        } else {
-          st[j] = *reinterpret_cast<const u32x4*>(p);
-        }
+        st[j] = *reinterpret_cast<const u32x4*>(p);
       }
     }
   };
   auto fetch_tau = [&](const unsigned* p) {
     if (ASM_LOADS && p) {
-      unsigned x;
-      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(x) : "v"(p) : "memory");
-      tg = x;
+      tg = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   auto park_tile = [&](char* dst) {
-    if (ASM_LOADS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      { unsigned x = tg; asm volatile("" : "+v"(x)); tg = x; }
-#pragma unroll
-      for (int j = 0; j < C::kLoads; ++j) {
-        u32x4 x = st[j];
-        asm volatile("" : "+v"(x));
-        st[j] = x;
-      }
-    }
+
 #pragma unroll
     for (int j = 0; j < C::kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };

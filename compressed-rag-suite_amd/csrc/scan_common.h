@@ -207,6 +207,24 @@ __device__ __forceinline__ const T* uniform_ptr(const T* p) {
   return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
 }
 
+// ---------------------------------------------------------------- LDS-DMA (global memory -> LDS, 16 bytes per lane)
+// global_load_lds_dwordx4 takes its LDS destination (wave-uniform base; lane i lands at base + 16 i) from M0.  The
+// statement is asm because the compiler's own waitcnt insertion would put a vmcnt(0) in front of every LDS read that
+// may alias an in-flight transfer -- the kernels count their transfers themselves.  M0 is SAVED AND RESTORED inside the
+// statement (no reserved register in a clobber list, nothing the compiler keeps in M0 is disturbed).  Wait states:
+// the two s_mov + s_nop 2 are the 5 states a v_readfirstlane-written SGPR base needs before a VMEM read of it, and
+// cover the 1 state between the write of M0 and the transfer.
+__device__ __forceinline__ void lds_dma16(unsigned lds_dst, unsigned voff, const void* sbase) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void lds_dma16(unsigned lds_dst, const void* vaddr) {   // per-lane 64-bit address
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(vaddr) : "memory");
+}
+
 // ---------------------------------------------------------------- threshold sharing across workgroups
 // Every wave's tau is the k-th best of a SUBSET of the rows, hence a lower bound on the global k-th
 // best.  Waves publish it with an agent-scope atomic max on an order-preserving integer image of

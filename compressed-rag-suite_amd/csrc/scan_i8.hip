@@ -88,12 +88,12 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
         const unsigned dst = dst0 + (unsigned)(j * kThreads * 16);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(src_off[j]), "s"(base) : "memory", "m0");
+        lds_dma16(dst, src_off[j], base);
       }
       if (wave == 0 && lane < TR / 4) {
         const float* sb = uniform_ptr(a.scales + (size_t)tile * TR);
         const unsigned off = (unsigned)lane * 16u, dst = sc_m0 + (unsigned)(buf * (TR * 4));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(sb) : "memory", "m0");
+        lds_dma16(dst, off, sb);
       }
     } else {
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
         off = off > last_chunk ? last_chunk : off;
         const char* p = slab + off;
         const unsigned dst = dst0 + (unsigned)(j * kThreads * 16);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(p) : "memory", "m0");
+        lds_dma16(dst, p);
       }
       if (wave == 0 && lane < TR) {   // the slab's one ragged tile (or past the end): ordinary loads, clamped rows
         const long row = min((long)tile * TR + lane, (long)a.n_rows - 1);
@@ -199,9 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     if (t + nwg < a.n_tiles) load_tile(t + nwg, cur ^ 1);
     WP_LAP(1);   // look-ahead issue
     if (tau_pub) {
-      unsigned x;
-      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(x) : "v"(tau_pub) : "memory");
-      tg = x;
+      tg = __hip_atomic_load(tau_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (wave_active) {
       const char* buf = tile_buf + cur * C::kTileBytes;

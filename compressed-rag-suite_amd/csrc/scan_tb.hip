@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
 #pragma unroll
       for (int j = 0; j < C::kLoads; ++j) {
         const unsigned dst = dst0 + (unsigned)(j * kT * 16);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(src_off[j]), "s"(base) : "memory", "m0");
+        lds_dma16(dst, src_off[j], base);
       }
     } else {   // the ragged last tile: clamp every lane to the slab's last 16 bytes (rows past the end never rank)
 #pragma unroll
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
         off = off > last_chunk ? last_chunk : off;
         const char* p = slab + off;
         const unsigned dst = dst0 + (unsigned)(j * kT * 16);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(p) : "memory", "m0");
+        lds_dma16(dst, p);
       }
     }
   };

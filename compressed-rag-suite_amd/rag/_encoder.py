@@ -117,6 +117,11 @@ class HipEncoder:
             dev32("embeddings.LayerNorm.bias").data_ptr(),
             ctypes.cast(self._layers, POINTER(EncoderLayer)))
         self._ws = None
+        # the same tensors in the order torch.ops.crs.encoder_forward takes them (csrc/torch_ops.cpp)
+        self._wlist = self._keep[-5:] + self._keep[:-5]     # embeddings first, then 12 tensors per layer
+        assert len(self._wlist) == 5 + 12 * shape.layers
+        self._desc_list = [shape.vocab_size, shape.hidden, shape.layers, shape.heads, shape.ffn, shape.max_pos,
+                           POOL_CLS if shape.pooling == "cls" else POOL_MEAN]
 
     def workspace_bytes(self, batch: int, seq: int) -> int:
         out = c_size_t(0)
@@ -152,12 +157,8 @@ class HipEncoder:
                 raise ValueError("q16_out needs normalize=True and return_hidden=False")
             if tuple(q16_out.shape) != (b, nat.padded_dim(self.shape.hidden, slab_type)) or q16_out.dtype != torch.float16:
                 raise ValueError("q16_out must be fp16 [batch, padded_dim]")
-            nat.check(nat.load().crs_encoder_forward_queries(byref(self.desc), byref(self.weights), nat._ptr(ids),
-                                                             nat._ptr(lens), b, s, nat._ptr(ws), ws.numel(), nat._ptr(out),
-                                                             nat._ptr(q16_out), slab_type, nat._stream_ptr()))
-            return out
         hidden = torch.empty((b, s, self.shape.hidden), dtype=torch.float32, device=self.device) if return_hidden else None
-        nat.check(nat.load().crs_encoder_forward(byref(self.desc), byref(self.weights), nat._ptr(ids), nat._ptr(lens),
-                                                 b, s, nat._ptr(ws), ws.numel(), nat._ptr(out),
-                                                 1 if normalize else 0, nat._ptr(hidden), nat._stream_ptr()))
+        with nat._translate():
+            nat.ops().encoder_forward(ids, lens, self._wlist, self._desc_list, float(self.shape.ln_eps), ws, out, q16_out,
+                                      int(slab_type), bool(normalize), hidden)
         return (out, hidden) if return_hidden else out

@@ -1,8 +1,11 @@
-"""ctypes binding of libcrs_hip.so (the C ABI in include/crs_hip.h).
+"""Bindings of the native library.
 
-PyTorch is used only as plumbing: device memory (``tensor.data_ptr()``), the current HIP stream
-and ``torch.distributed``.  There is no CPU fallback anywhere in this module: if the shared
-library is missing, or there is no GPU, the calls raise.
+Compute calls go through the PyTorch-ROCm custom ops ``torch.ops.crs.*`` that csrc/torch_ops.cpp registers with
+TORCH_LIBRARY (libcrs_torch.so; tensors in, current HIP stream) over the C ABI of libcrs_hip.so
+(include/crs_hip.h, include/crs_encoder.h).  The C ABI itself is bound with ctypes for the host-side
+queries (row padding, workspace sizes, plan description, the timing hook) and stays the drop-in boundary for
+non-torch hosts.  There is no CPU fallback anywhere in this module: if a shared library is
+missing, or there is no GPU, the calls raise.
 """
 from __future__ import annotations
 
@@ -12,6 +15,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libcrs_hip.so")  # override: A/B builds
+TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libcrs_torch.so")
 
 SLAB_F16 = 0
 SLAB_I8 = 1
@@ -79,6 +83,34 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+_ops = None
+
+
+def ops():
+    """``torch.ops.crs`` -- the PyTorch custom ops of libcrs_torch.so (loaded once; raises when it has not been built)."""
+    global _ops
+    if _ops is None:
+        load()                                  # the C-ABI library first (libcrs_torch.so links against it by file name)
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise NativeError(f"{TORCH_LIB_PATH} is missing: build it with `make -C {os.path.dirname(TORCH_LIB_PATH)}` "
+                              f"-- this path has no CPU fallback")
+        import torch
+        torch.ops.load_library(TORCH_LIB_PATH)
+        _ops = torch.ops.crs
+    return _ops
+
+
+class _translate:
+    """torch custom ops raise RuntimeError (TORCH_CHECK); the callers of this module catch NativeError."""
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and issubclass(et, RuntimeError) and not issubclass(et, NativeError):
+            raise NativeError(str(ev).split("\n")[0]) from ev
+        return False
+
+
 def exported_symbols():
     return sorted(_SIGNATURES)
 
@@ -112,9 +144,10 @@ def require_gpu():
 # ----------------------------------------------------------------------------- wrappers
 def slab_append_f32(emb, slab, row0: int, slab_type: int, scales=None, shadow=None) -> None:
     """emb: cuda fp32 [n, dim]; slab: cuda fp16/int8 [cap, pdim]; writes rows row0..row0+n."""
-    n, dim = emb.shape
-    check(load().crs_slab_append_f32(_ptr(emb), n, dim, slab_type, _ptr(slab), _ptr(scales),
-                                     _ptr(shadow), row0, _stream_ptr()))
+    if emb.shape[0] == 0:
+        return
+    with _translate():
+        ops().slab_append(emb, slab, scales, shadow, int(row0))
 
 
 def queries_to_f16(q32, slab_type: int = SLAB_F16, out=None):
@@ -122,7 +155,9 @@ def queries_to_f16(q32, slab_type: int = SLAB_F16, out=None):
     nq, dim = q32.shape
     if out is None:
         out = torch.empty((nq, padded_dim(dim, slab_type)), dtype=torch.float16, device=q32.device)
-    check(load().crs_queries_to_f16(_ptr(q32), nq, dim, slab_type, _ptr(out), _stream_ptr()))
+    if nq:
+        with _translate():
+            ops().queries_to_f16(q32, out, int(slab_type))
     return out
 
 
@@ -144,9 +179,8 @@ def cosine_topk(q16, slab, n_rows: int, dim: int, k: int, *, slab_type: int = SL
         out_scores = torch.empty((nq, k), dtype=torch.float32, device=q16.device)
     if out_ids is None:
         out_ids = torch.empty((nq, k), dtype=torch.int64, device=q16.device)
-    check(load().crs_cosine_topk(_ptr(q16), nq, dim, slab_type, _ptr(slab), _ptr(scales), n_rows, k,
-                                 id_base, _ptr(workspace), workspace.numel(), _ptr(out_scores),
-                                 _ptr(out_ids), _stream_ptr()))
+    with _translate():
+        ops().cosine_topk_out(q16, slab, scales, int(n_rows), int(dim), int(k), int(id_base), workspace, out_scores, out_ids)
     return out_scores, out_ids
 
 
@@ -156,12 +190,13 @@ def merge_topk(scores, ids, k_out: int, out_scores=None, out_ids=None):
     g, nq, k_in = scores.shape
     out_s = out_scores if out_scores is not None else torch.empty((nq, k_out), dtype=torch.float32, device=scores.device)
     out_i = out_ids if out_ids is not None else torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
-    check(load().crs_merge_topk(_ptr(scores), _ptr(ids), g, nq, k_in, k_out, _ptr(out_s), _ptr(out_i),
-                                _stream_ptr()))
+    with _translate():
+        ops().merge_topk_out(scores, ids, int(k_out), out_s, out_i)
     return out_s, out_i
 
 
 def rescore_f32(q32, shadow, n_rows: int, id_base: int, scores, ids) -> None:
+    """In-place variant kept from ABI v1 (C ABI only): re-score all k candidates and re-sort each row."""
     nq, dim = q32.shape
     k = scores.shape[1]
     check(load().crs_rescore_f32(_ptr(q32), nq, dim, _ptr(shadow), n_rows, id_base, k, _ptr(scores),
@@ -173,13 +208,12 @@ def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out
     fp16/int8 slab) -> the k_out best by <q32, shadow[id - id_base]> (score desc, id asc)."""
     import torch
     nq, dim = q32.shape
-    k_in = cand_ids.shape[1]
     if out_scores is None:
         out_scores = torch.empty((nq, k_out), dtype=torch.float32, device=q32.device)
     if out_ids is None:
         out_ids = torch.empty((nq, k_out), dtype=torch.int64, device=q32.device)
-    check(load().crs_refine_f32(_ptr(q32), nq, dim, _ptr(shadow), n_rows, id_base, _ptr(cand_ids), k_in, k_out,
-                                _ptr(out_scores), _ptr(out_ids), _stream_ptr()))
+    with _translate():
+        ops().refine_f32_out(q32, shadow, int(n_rows), int(id_base), cand_ids, int(k_out), out_scores, out_ids)
     return out_scores, out_ids
 
 
@@ -205,7 +239,8 @@ def merge_topk_wire(gathered, nlists: int, nq: int, k_in: int, k_out: int, out_s
     import torch
     out_s = out_scores if out_scores is not None else torch.empty((nq, k_out), dtype=torch.float32, device=gathered.device)
     out_i = out_ids if out_ids is not None else torch.empty((nq, k_out), dtype=torch.int64, device=gathered.device)
-    check(load().crs_merge_topk_wire(_ptr(gathered), nlists, nq, k_in, k_out, _ptr(out_s), _ptr(out_i), _stream_ptr()))
+    with _translate():
+        ops().merge_topk_wire_out(gathered, int(nlists), int(nq), int(k_in), int(k_out), out_s, out_i)
     return out_s, out_i
 
 

@@ -71,30 +71,56 @@ def synthetic_weights(shape, seed: int = 0, scale: float = 0.05) -> Dict[str, np
 
 
 def _load_local_dir(path: str):
-    """(ModelShape, weights dict, tokenizer) from a sentence-transformers style directory."""
+    """(ModelShape, weights dict, tokenizer, pre_lower, normalize_module) from a sentence-transformers directory.
+
+    What ``SentenceTransformer(path)`` (reference rag/embedding.py:33) assembles from the same files:
+    modules.json lists the pipeline (Transformer at "", Pooling at "1_Pooling", optional Normalize); the
+    Transformer module reads config.json + model.safetensors + the tokenizer files and takes
+    ``max_seq_length`` / ``do_lower_case`` from sentence_bert_config.json -- the latter is only an extra
+    ``str.lower()`` pass BEFORE the tokenizer, whose own casing rule comes from its own files."""
     from safetensors.numpy import load_file
     from rag._encoder import ModelShape
-    with open(os.path.join(path, "config.json")) as fh:
+    from rag.tokenizer import tokenizer_from_model_dir
+    tr_dir, pool_dir, has_normalize = path, os.path.join(path, "1_Pooling"), False
+    mj = os.path.join(path, "modules.json")
+    if os.path.exists(mj):
+        with open(mj) as fh:
+            for mod in json.load(fh):
+                kind = str(mod.get("type", "")).rsplit(".", 1)[-1]
+                sub = os.path.join(path, mod.get("path", "") or "")
+                if kind == "Transformer":
+                    tr_dir = sub
+                elif kind == "Pooling":
+                    pool_dir = sub
+                elif kind == "Normalize":
+                    has_normalize = True
+                elif kind:
+                    raise NotImplementedError(f"sentence-transformers module '{mod.get('type')}' is not supported by this encoder")
+    with open(os.path.join(tr_dir, "config.json")) as fh:
         cfg = json.load(fh)
-    max_seq, pooling, lower = cfg.get("max_position_embeddings", 512), "mean", True
-    sb = os.path.join(path, "sentence_bert_config.json")
+    max_seq, pooling, pre_lower = cfg.get("max_position_embeddings", 512), "mean", False
+    sb = os.path.join(tr_dir, "sentence_bert_config.json")
     if os.path.exists(sb):
         with open(sb) as fh:
             sbc = json.load(fh)
-        max_seq = sbc.get("max_seq_length", max_seq)
-        lower = sbc.get("do_lower_case", lower)
-    pc = os.path.join(path, "1_Pooling", "config.json")
+        max_seq = sbc.get("max_seq_length", max_seq) or max_seq
+        pre_lower = bool(sbc.get("do_lower_case", False))
+    pc = os.path.join(pool_dir, "config.json")
     if os.path.exists(pc):
         with open(pc) as fh:
-            if json.load(fh).get("pooling_mode_cls_token"):
-                pooling = "cls"
+            pcfg = json.load(fh)
+        modes = [m for m in ("cls_token", "mean_tokens", "max_tokens", "mean_sqrt_len_tokens", "weightedmean_tokens", "lasttoken")
+                 if pcfg.get("pooling_mode_" + m)]
+        if modes == ["cls_token"]:
+            pooling = "cls"
+        elif modes not in ([], ["mean_tokens"]):
+            raise NotImplementedError(f"pooling mode(s) {modes} are not supported (mean and CLS are)")
     shape = ModelShape(cfg["vocab_size"], cfg["hidden_size"], cfg["num_hidden_layers"], cfg["num_attention_heads"],
                        cfg["intermediate_size"], cfg["max_position_embeddings"], cfg.get("layer_norm_eps", 1e-12),
                        pooling, min(max_seq, cfg["max_position_embeddings"]))
-    raw = load_file(os.path.join(path, "model.safetensors"))
+    raw = load_file(os.path.join(tr_dir, "model.safetensors"))
     weights = {(k[5:] if k.startswith("bert.") else k): np.asarray(v, dtype=np.float32) for k, v in raw.items()}
-    tok = make_wordpiece_tokenizer(os.path.join(path, "vocab.txt"), lower=lower)
-    return shape, weights, tok
+    return shape, weights, tokenizer_from_model_dir(tr_dir), pre_lower, has_normalize
 
 
 class EmbeddingModel:
@@ -106,6 +132,7 @@ class EmbeddingModel:
         self.normalize = config.get('normalize', True)
         self.device = self._get_device(config.get('device', 'cuda'))
         logger.info(f"Loading embedding model: {self.model_name}")
+        self._pre_lower = False      # sentence_bert_config.json do_lower_case: an extra str.lower() before the tokenizer
         shape, weights, self.tokenizer = self._resolve(config)
         if config.get('max_seq_length'):
             from dataclasses import replace
@@ -135,7 +162,8 @@ class EmbeddingModel:
                      os.path.join(os.environ.get("CRS_MODEL_DIR", ""), os.path.basename(name)) if os.environ.get("CRS_MODEL_DIR") else None):
             if cand and os.path.isdir(cand) and os.path.exists(os.path.join(cand, "model.safetensors")):
                 logger.info(f"Loading local checkpoint {cand}")
-                return _load_local_dir(cand)
+                shape, weights, tok, self._pre_lower, _has_norm = _load_local_dir(cand)
+                return shape, weights, tok
         key = name.split(":", 1)[1] if name.startswith("synthetic:") else os.path.basename(name)
         key = _ALIASES.get(key.lower(), key.lower())
         if key in _KNOWN and (name.startswith("synthetic:") or os.environ.get("CRS_ALLOW_SYNTHETIC_WEIGHTS") == "1"):
@@ -149,7 +177,11 @@ class EmbeddingModel:
 
     # ---- encoding ------------------------------------------------------------------------------
     def tokenize(self, texts: List[str]):
-        """-> list of id lists ([CLS] ... [SEP], truncated to max_seq)."""
+        """-> list of id lists ([CLS] ... [SEP], truncated to max_seq).  Text is stripped (and lower-cased when the
+        model's sentence_bert_config.json says so) first, as sentence-transformers' Transformer.tokenize does."""
+        texts = [str(t).strip() for t in texts]
+        if self._pre_lower:
+            texts = [t.lower() for t in texts]
         if hasattr(self.tokenizer, "encode_batch"):
             return self.tokenizer.encode_batch(texts, self.shape.max_seq)
         return [self.tokenizer.encode(t, self.shape.max_seq) for t in texts]

@@ -30,7 +30,9 @@ def _is_cjk(cp: int) -> bool:
             0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
 
 
-def basic_tokenize(text: str, lower: bool = True) -> List[str]:
+def basic_tokenize(text: str, lower: bool = True, strip_accents=None) -> List[str]:
+    """BERT basic tokenisation.  `strip_accents=None` follows the lower-casing flag (the BertNormalizer rule)."""
+    strip = lower if strip_accents is None else bool(strip_accents)
     cleaned = []
     for ch in text:
         cp = ord(ch)
@@ -46,6 +48,7 @@ def basic_tokenize(text: str, lower: bool = True) -> List[str]:
     for tok in "".join(cleaned).split():
         if lower:
             tok = tok.lower()
+        if strip:
             tok = "".join(c for c in unicodedata.normalize("NFD", tok) if unicodedata.category(c) != "Mn")
         cur = ""
         for ch in tok:
@@ -62,16 +65,17 @@ def basic_tokenize(text: str, lower: bool = True) -> List[str]:
 
 
 class WordPieceTokenizer:
-    def __init__(self, vocab: Dict[str, int], lower: bool = True, unk="[UNK]", cls="[CLS]", sep="[SEP]", pad="[PAD]"):
-        self.vocab, self.lower = vocab, lower
+    def __init__(self, vocab: Dict[str, int], lower: bool = True, unk="[UNK]", cls="[CLS]", sep="[SEP]", pad="[PAD]",
+                 strip_accents=None):
+        self.vocab, self.lower, self.strip_accents = vocab, lower, strip_accents
         self.unk_id, self.cls_id, self.sep_id = vocab[unk], vocab[cls], vocab[sep]
         self.pad_id = vocab.get(pad, 0)
 
     @classmethod
-    def from_vocab_file(cls, path: str, lower: bool = True) -> "WordPieceTokenizer":
+    def from_vocab_file(cls, path: str, lower: bool = True, strip_accents=None) -> "WordPieceTokenizer":
         with open(path, encoding="utf-8") as fh:
             vocab = {line.rstrip("\n"): i for i, line in enumerate(fh)}
-        return cls(vocab, lower=lower)
+        return cls(vocab, lower=lower, strip_accents=strip_accents)
 
     def _wordpiece(self, word: str) -> List[int]:
         if len(word) > 100:
@@ -93,7 +97,7 @@ class WordPieceTokenizer:
 
     def encode(self, text: str, max_len: int) -> List[int]:
         ids: List[int] = []
-        for w in basic_tokenize(text, self.lower):
+        for w in basic_tokenize(text, self.lower, self.strip_accents):
             ids.extend(self._wordpiece(w))
             if len(ids) >= max_len - 2:
                 break
@@ -112,24 +116,37 @@ class FastWordPieceTokenizer:
         self._max_len = None
 
     @classmethod
-    def from_vocab(cls, vocab: Dict[str, int], lower: bool = True, unk="[UNK]", cls_tok="[CLS]", sep="[SEP]", pad="[PAD]"):
+    def from_tokenizer_json(cls, path: str) -> "FastWordPieceTokenizer":
+        """The model directory's own tokenizer.json, exactly as the reference's backend loads it (normaliser,
+        casing and accent rules included); padding off, truncation set per call."""
+        from tokenizers import Tokenizer
+        tok = Tokenizer.from_file(path)
+        tok.no_padding()
+        ids = [tok.token_to_id(t) for t in ("[CLS]", "[SEP]", "[PAD]")]
+        if ids[0] is None or ids[1] is None:
+            raise ValueError(f"{path}: not a BERT-style tokenizer ([CLS]/[SEP] missing)")
+        return cls(tok, ids[0], ids[1], ids[2] if ids[2] is not None else 0)
+
+    @classmethod
+    def from_vocab(cls, vocab: Dict[str, int], lower: bool = True, unk="[UNK]", cls_tok="[CLS]", sep="[SEP]", pad="[PAD]",
+                   strip_accents=None):
         from tokenizers import Tokenizer
         from tokenizers.models import WordPiece
         from tokenizers.normalizers import BertNormalizer
         from tokenizers.pre_tokenizers import BertPreTokenizer
         from tokenizers.processors import TemplateProcessing
         tok = Tokenizer(WordPiece(vocab, unk_token=unk, max_input_chars_per_word=100))
-        tok.normalizer = BertNormalizer(clean_text=True, handle_chinese_chars=True, strip_accents=None, lowercase=lower)
+        tok.normalizer = BertNormalizer(clean_text=True, handle_chinese_chars=True, strip_accents=strip_accents, lowercase=lower)
         tok.pre_tokenizer = BertPreTokenizer()
         tok.post_processor = TemplateProcessing(single=f"{cls_tok} $A {sep}",
                                                 special_tokens=[(cls_tok, vocab[cls_tok]), (sep, vocab[sep])])
         return cls(tok, vocab[cls_tok], vocab[sep], vocab.get(pad, 0))
 
     @classmethod
-    def from_vocab_file(cls, path: str, lower: bool = True) -> "FastWordPieceTokenizer":
+    def from_vocab_file(cls, path: str, lower: bool = True, strip_accents=None) -> "FastWordPieceTokenizer":
         with open(path, encoding="utf-8") as fh:
             vocab = {line.rstrip("\n"): i for i, line in enumerate(fh)}
-        return cls.from_vocab(vocab, lower=lower)
+        return cls.from_vocab(vocab, lower=lower, strip_accents=strip_accents)
 
     def _limit(self, max_len: int):
         if self._max_len != max_len:
@@ -145,15 +162,38 @@ class FastWordPieceTokenizer:
         return [e.ids for e in self._tok.encode_batch(list(texts))]
 
 
-def make_wordpiece_tokenizer(vocab_path: str, lower: bool = True):
+def make_wordpiece_tokenizer(vocab_path: str, lower: bool = True, strip_accents=None):
     """FastWordPieceTokenizer when the `tokenizers` library is importable (CRS_TOKENIZER=python forces the pure
     Python restatement), else WordPieceTokenizer."""
     if os.environ.get("CRS_TOKENIZER", "") != "python":
         try:
-            return FastWordPieceTokenizer.from_vocab_file(vocab_path, lower=lower)
+            return FastWordPieceTokenizer.from_vocab_file(vocab_path, lower=lower, strip_accents=strip_accents)
         except ImportError:
             pass
-    return WordPieceTokenizer.from_vocab_file(vocab_path, lower=lower)
+    return WordPieceTokenizer.from_vocab_file(vocab_path, lower=lower, strip_accents=strip_accents)
+
+
+def tokenizer_from_model_dir(path: str):
+    """The tokeniser a HuggingFace BERT checkpoint directory describes.  Casing comes from the TOKENIZER's own
+    files, as in the reference stack (sentence-transformers hands the text to the HF tokenizer; the published
+    all-MiniLM-L6-v2 ships sentence_bert_config.json do_lower_case=false next to an uncased vocab whose tokenizer
+    lower-cases): tokenizer.json when the `tokenizers` library can load it, else vocab.txt with
+    tokenizer_config.json's do_lower_case / strip_accents (absent -> lower-case, the uncased default)."""
+    import json
+    tj = os.path.join(path, "tokenizer.json")
+    if os.path.exists(tj) and os.environ.get("CRS_TOKENIZER", "") != "python":
+        try:
+            return FastWordPieceTokenizer.from_tokenizer_json(tj)
+        except ImportError:
+            pass
+    lower, strip = True, None
+    tc = os.path.join(path, "tokenizer_config.json")
+    if os.path.exists(tc):
+        with open(tc) as fh:
+            cfg = json.load(fh)
+        lower = bool(cfg.get("do_lower_case", True))
+        strip = cfg.get("strip_accents", None)
+    return make_wordpiece_tokenizer(os.path.join(path, "vocab.txt"), lower=lower, strip_accents=strip)
 
 
 class HashTokenizer:

@@ -109,6 +109,21 @@ def test_library_exports_every_declared_symbol():
     assert [lib.crs_padded_dim(d) for d in (1, 100, 128, 384, 768, 1000)] == [128, 128, 128, 384, 768, 1024]
 
 
+def test_torch_custom_ops_are_registered():
+    """libcrs_torch.so loads on a CPU-only host and registers every op of the north_star's
+    'PyTorch-ROCm custom ops' boundary under torch.ops.crs (HIP backend only: no CPU kernel exists)."""
+    import torch
+    from rag import _native as nat
+    ops = nat.ops()
+    for name in ("slab_append", "queries_to_f16", "cosine_topk", "cosine_topk_out", "refine_f32", "refine_f32_out",
+                 "merge_topk", "merge_topk_out", "merge_topk_wire_out", "encoder_forward"):
+        assert hasattr(ops, name), name
+    schema = str(torch.ops.crs.cosine_topk.default._schema)
+    assert "Tensor q16, Tensor slab, Tensor? scales, int n_rows, int dim, int k, int id_base" in schema
+    with pytest.raises((RuntimeError, NotImplementedError)):       # no CPU implementation, by design
+        ops.merge_topk(torch.zeros(2, 3, 4), torch.zeros(2, 3, 4, dtype=torch.long), 2)
+
+
 def test_argument_validation_without_gpu():
     """Pure argument checks return error codes before any HIP call."""
     from rag import _native as nat
@@ -259,3 +274,68 @@ def test_fast_tokenizer_backend_matches_the_restatement(tmp_path):
         for t, g in zip(texts, got):
             assert g == slow.encode(t, max_len), (t, max_len)
             assert fast.encode(t, max_len) == g
+
+
+# ---- local sentence-transformers directory loader (f1) -----------------------------------------------------
+@pytest.mark.parametrize("tokenizer_json", [False, True])
+@pytest.mark.parametrize("pooling", ["mean", "cls"])
+def test_load_local_dir_reads_the_sentence_transformers_layout(tmp_path, pooling, tokenizer_json):
+    """config.json / model.safetensors ('bert.' prefix) / vocab.txt or tokenizer.json / sentence_bert_config.json /
+    modules.json / 1_Pooling/config.json -- what SentenceTransformer(path) reads (/root/reference/rag/embedding.py:33)."""
+    from _modeldir import write_model_dir
+    from rag.embedding import _load_local_dir
+    d = str(tmp_path / "m")
+    weights, cfg = write_model_dir(d, pooling=pooling, bert_prefix=True, sbert_lower=False, tok_lower=True,
+                                   tokenizer_json=tokenizer_json)
+    shape, w, tok, pre_lower, has_norm = _load_local_dir(d)
+    assert (shape.hidden, shape.layers, shape.heads, shape.ffn, shape.vocab_size) == (64, 2, 4, 128, cfg["vocab_size"])
+    assert shape.pooling == pooling and shape.max_seq == 48 and shape.max_pos == 64
+    assert pre_lower is False and has_norm is True
+    assert set(weights) <= set(w) and not any(k.startswith("bert.") for k in w)
+    for k in weights:
+        assert np.array_equal(w[k], weights[k])
+    # casing comes from the TOKENIZER's files, not from sentence_bert_config.json (do_lower_case=false there):
+    a, b = tok.encode("The Quick Brown FOX", 48), tok.encode("the quick brown fox", 48)
+    assert a == b
+    vocab = {t: i for i, t in enumerate(open(os.path.join(d, "vocab.txt"), encoding="utf-8").read().split("\n"))}
+    assert a == [vocab["[CLS]"], vocab["the"], vocab["quick"], vocab["brown"], vocab["fox"], vocab["[SEP]"]]
+    assert tok.encode("Caf\u00e9 r\u00e9sum\u00e9", 48) == tok.encode("cafe resume", 48)          # accents stripped with lower-casing
+    assert len(tok.encode("the " * 100, 48)) == 48                                                # truncation to max_seq_length
+
+
+def test_local_dir_tokenizers_agree(tmp_path, monkeypatch):
+    """vocab.txt through the pure-Python restatement == through the `tokenizers` library == tokenizer.json."""
+    from _modeldir import write_model_dir
+    from rag.tokenizer import tokenizer_from_model_dir
+    d = str(tmp_path / "m")
+    write_model_dir(d, tokenizer_json=True)
+    fast_json = tokenizer_from_model_dir(d)
+    os.remove(os.path.join(d, "tokenizer.json"))
+    fast_vocab = tokenizer_from_model_dir(d)
+    monkeypatch.setenv("CRS_TOKENIZER", "python")
+    slow = tokenizer_from_model_dir(d)
+    assert type(slow).__name__ == "WordPieceTokenizer" and type(fast_vocab).__name__ == "FastWordPieceTokenizer"
+    for text in ["The quick brown fox jumps over the lazy dog.", "Retrieval-augmented generation, embeds CHUNKS!",
+                 "unknownword jumped quickly", "caf\u00e9 na\u00efve", "", "a" * 120, "vector   store\tcosine\nsimilarity?"]:
+        ids = slow.encode(text, 32)
+        assert ids == fast_vocab.encode(text, 32) == fast_json.encode(text, 32), text
+
+
+def test_cased_tokenizer_config_is_respected(tmp_path):
+    from _modeldir import write_model_dir
+    from rag.tokenizer import tokenizer_from_model_dir
+    d = str(tmp_path / "m")
+    write_model_dir(d, tok_lower=False)
+    tok = tokenizer_from_model_dir(d)
+    assert tok.encode("The", 16) != tok.encode("the", 16)
+
+
+def test_unsupported_pooling_mode_raises(tmp_path):
+    import json as _json
+    from _modeldir import write_model_dir
+    from rag.embedding import _load_local_dir
+    d = str(tmp_path / "m")
+    write_model_dir(d)
+    _json.dump({"pooling_mode_max_tokens": True}, open(os.path.join(d, "1_Pooling", "config.json"), "w"))
+    with pytest.raises(NotImplementedError):
+        _load_local_dir(d)
