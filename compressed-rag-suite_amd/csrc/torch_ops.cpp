@@ -14,8 +14,8 @@
 // The C ABI (include/crs_hip.h, include/crs_encoder.h) stays the drop-in boundary for non-torch hosts
 // (INTEGRATION.md section 2); this file only adapts it.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // torch-ROCm tensors carry DeviceType "cuda": the masquerading guard/stream
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <tuple>
@@ -28,7 +28,7 @@ namespace {
 
 using at::Tensor;
 
-void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": libcrs_hip error ", rc, ": ", crs_last_error()); }
 
@@ -62,7 +62,7 @@ void slab_append(const Tensor& emb, Tensor slab, c10::optional<Tensor> scales, c
     want(*shadow, at::kFloat, "shadow");
     TORCH_CHECK(shadow->dim() == 2 && shadow->size(1) == dim && shadow->size(0) >= row0 + n, "shadow must be fp32 [>= row0 + n, dim]");
   }
-  c10::hip::HIPGuard g(emb.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(emb.device());
   ok(crs_slab_append_f32(emb.data_ptr<float>(), n, dim, st, slab.data_ptr(), (float*)opt_ptr(scales), (float*)opt_ptr(shadow), row0,
                          cur_stream(emb)), "crs::slab_append");
 }
@@ -72,7 +72,7 @@ void queries_to_f16(const Tensor& q32, Tensor out16, int64_t slab_type) {
   want(out16, at::kHalf, "out16");
   TORCH_CHECK(q32.dim() == 2 && out16.dim() == 2 && out16.size(0) == q32.size(0) &&
                   out16.size(1) == crs_row_elems((int)q32.size(1), (int)slab_type), "out16 must be [nq, crs_row_elems(dim, slab_type)]");
-  c10::hip::HIPGuard g(q32.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
   ok(crs_queries_to_f16(q32.data_ptr<float>(), (int)q32.size(0), (int)q32.size(1), (int)slab_type, out16.data_ptr(), cur_stream(q32)),
      "crs::queries_to_f16");
 }
@@ -95,7 +95,7 @@ void cosine_topk_out(const Tensor& q16, const Tensor& slab, c10::optional<Tensor
     TORCH_CHECK(scales.has_value(), "int8 slab needs scales");
     want(*scales, at::kFloat, "scales");
   }
-  c10::hip::HIPGuard g(q16.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q16.device());
   ok(crs_cosine_topk(q16.data_ptr(), (int)nq, (int)dim, st, slab.data_ptr(), (const float*)opt_ptr(scales), n_rows, (int)k, id_base,
                      workspace.data_ptr(), (size_t)workspace.nbytes(), out_scores.data_ptr<float>(), out_ids.data_ptr<int64_t>(),
                      cur_stream(q16)), "crs::cosine_topk");
@@ -106,7 +106,7 @@ std::tuple<Tensor, Tensor> cosine_topk(const Tensor& q16, const Tensor& slab, c1
   TORCH_CHECK(q16.dim() == 2, "q16 must be [nq, pdim]");
   size_t need = 0;
   ok(crs_scan_workspace_bytes((int)q16.size(0), (int)dim, (int)k, n_rows, &need), "crs::cosine_topk (workspace)");
-  c10::hip::HIPGuard g(q16.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q16.device());
   Tensor ws = at::empty({(int64_t)need}, q16.options().dtype(at::kByte));
   Tensor s = at::empty({q16.size(0), k}, q16.options().dtype(at::kFloat));
   Tensor i = at::empty({q16.size(0), k}, q16.options().dtype(at::kLong));
@@ -124,7 +124,7 @@ void refine_f32_out(const Tensor& q32, const Tensor& shadow, int64_t n_rows, int
   TORCH_CHECK(q32.dim() == 2 && shadow.dim() == 2 && cand_ids.dim() == 2 && shadow.size(1) == q32.size(1) &&
                   cand_ids.size(0) == q32.size(0) && n_rows <= shadow.size(0), "q32 [nq, dim], shadow [>= n_rows, dim], cand_ids [nq, k_in]");
   TORCH_CHECK(out_scores.numel() == q32.size(0) * k_out && out_ids.numel() == q32.size(0) * k_out, "outputs must hold [nq, k_out]");
-  c10::hip::HIPGuard g(q32.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
   ok(crs_refine_f32(q32.data_ptr<float>(), (int)q32.size(0), (int)q32.size(1), shadow.data_ptr<float>(), n_rows, id_base,
                     cand_ids.data_ptr<int64_t>(), (int)cand_ids.size(1), (int)k_out, out_scores.data_ptr<float>(),
                     out_ids.data_ptr<int64_t>(), cur_stream(q32)), "crs::refine_f32");
@@ -132,7 +132,7 @@ void refine_f32_out(const Tensor& q32, const Tensor& shadow, int64_t n_rows, int
 
 std::tuple<Tensor, Tensor> refine_f32(const Tensor& q32, const Tensor& shadow, int64_t n_rows, int64_t id_base, const Tensor& cand_ids,
                                       int64_t k_out) {
-  c10::hip::HIPGuard g(q32.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
   Tensor s = at::empty({q32.size(0), k_out}, q32.options().dtype(at::kFloat));
   Tensor i = at::empty({q32.size(0), k_out}, q32.options().dtype(at::kLong));
   refine_f32_out(q32, shadow, n_rows, id_base, cand_ids, k_out, s, i);
@@ -146,14 +146,14 @@ void merge_topk_out(const Tensor& scores, const Tensor& ids, int64_t k_out, Tens
   want(out_ids, at::kLong, "out_ids");
   TORCH_CHECK(scores.dim() == 3 && ids.sizes() == scores.sizes(), "scores / ids must be [nlists, nq, k_in]");
   TORCH_CHECK(out_scores.numel() == scores.size(1) * k_out && out_ids.numel() == scores.size(1) * k_out, "outputs must hold [nq, k_out]");
-  c10::hip::HIPGuard g(scores.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(scores.device());
   ok(crs_merge_topk(scores.data_ptr<float>(), ids.data_ptr<int64_t>(), (int)scores.size(0), (int)scores.size(1), (int)scores.size(2),
                     (int)k_out, out_scores.data_ptr<float>(), out_ids.data_ptr<int64_t>(), cur_stream(scores)), "crs::merge_topk");
 }
 
 std::tuple<Tensor, Tensor> merge_topk(const Tensor& scores, const Tensor& ids, int64_t k_out) {
   TORCH_CHECK(scores.dim() == 3, "scores must be [nlists, nq, k_in]");
-  c10::hip::HIPGuard g(scores.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(scores.device());
   Tensor s = at::empty({scores.size(1), k_out}, scores.options().dtype(at::kFloat));
   Tensor i = at::empty({scores.size(1), k_out}, scores.options().dtype(at::kLong));
   merge_topk_out(scores, ids, k_out, s, i);
@@ -166,7 +166,7 @@ void merge_topk_wire_out(const Tensor& wire, int64_t nlists, int64_t nq, int64_t
   want(out_scores, at::kFloat, "out_scores");
   want(out_ids, at::kLong, "out_ids");
   TORCH_CHECK(out_scores.numel() == nq * k_out && out_ids.numel() == nq * k_out, "outputs must hold [nq, k_out]");
-  c10::hip::HIPGuard g(wire.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(wire.device());
   ok(crs_merge_topk_wire(wire.data_ptr(), (int)nlists, (int)nq, (int)k_in, (int)k_out, out_scores.data_ptr<float>(),
                          out_ids.data_ptr<int64_t>(), cur_stream(wire)), "crs::merge_topk_wire");
 }
@@ -195,7 +195,7 @@ void encoder_forward(const Tensor& ids, const Tensor& lens, at::TensorList weigh
   crs_encoder_weights cw{(const float*)weights[0].data_ptr(), (const float*)weights[1].data_ptr(), (const float*)weights[2].data_ptr(),
                          (const float*)weights[3].data_ptr(), (const float*)weights[4].data_ptr(), layers.data()};
   const int b = (int)ids.size(0), s = (int)ids.size(1);
-  c10::hip::HIPGuard g(ids.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(ids.device());
   if (q16_out.has_value() && q16_out->defined()) {
     want(*q16_out, at::kHalf, "q16_out");
     TORCH_CHECK(normalize && !(hidden_out.has_value() && hidden_out->defined()), "q16_out needs normalize=True and no hidden_out");

@@ -10,6 +10,12 @@ What pins what:
       outputs of the container-local transformers.BertModel (the library the reference's
       sentence-transformers wraps; random-init, weights from oracle/encoder_ref.make_weights)
       + the published Pooling / Normalize steps.  -> pins oracle/encoder_ref.py.
+  clean_text.json
+      outputs of the reference's own DocumentProcessor (/root/reference/rag/document_processing.py:129-217:
+      _clean_text / process_string / process_text / extract_sections), loaded standalone (PyPDF2 is optional
+      there, :8-11).  -> pins the product's rag/document_processing.py bit-for-bit.
+      The reference's rag/chunking.py raises ImportError at import without nltk (:10-20); loading it would
+      need a stand-in module, so the chunker stays "parity unpinned" (DESIGN section 5).
   scan_g2.npz
       exact top-k from an independent torch fp64 matmul + stable sort (ChromaDB itself is not
       installable here: the search boundary stays "parity unpinned").
@@ -209,8 +215,56 @@ def gen_scan():
                         scores=torch.gather(full, 1, order).numpy().astype(np.float32))
 
 
+def gen_clean_text():
+    """tests/golden/clean_text.json from the reference's DocumentProcessor."""
+    import tempfile
+    spec = importlib.util.spec_from_file_location("_ref_docproc", os.path.join(REF, "rag", "document_processing.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(77)
+    raw = [
+        "", "   ", "a  b\n\n c\t d", "12", " 12 ", "x \n 12 \n y", "Page 3 of the report", "see page 12 and PAGE 7.",
+        "Prior work [12] and [3], also (Smith et al., 2020) and (see Fig. 2) but (in 19999 cases) too.",
+        "Visit http://example.com/a?b=1 or https://x.org. Then continue", "no url at all",
+        "ef\u00ef\u00acne \u00ef\u00ac\u201aow \ufb01x \ufb02y \u201cquoted\u201d \u2018single\u2019",
+        "\"dq\" 'sq' it's", "weird , \"'\").replace( artefact", "(2020)", "[1][2][3]", "(a (b 2021) c)",
+        "Multi\n\nparagraph text\n\nwith   blank    lines\n\n\nand a trailing page number\n\n14\n",
+        "Intro\f second page 2024 \f third",
+    ]
+    for _ in range(25):      # seeded mixes of the above ingredients
+        parts = []
+        for _ in range(int(rng.integers(2, 8))):
+            parts.append(str(rng.choice(["alpha beta", "Page 9", "[7]", "(Doe 1999)", "https://a.b/c", "\n\n", "  ", "\u00ef\u00ac", "gamma.",
+                                         "12", "\t", "(no year)", "delta [x]", "Section 2 Methods", "\u00ef\u00ac\u201a"])))
+        raw.append(" ".join(parts))
+    cases = []
+    for cfg in ({}, {"remove_headers": False}, {"remove_citations": False}, {"remove_headers": False, "remove_citations": False}):
+        dp = m.DocumentProcessor(dict(cfg))
+        for t in raw:
+            cases.append({"config": cfg, "input": t, "clean": dp._clean_text(t), "process_string": dp.process_string(t)})
+    dp = m.DocumentProcessor({})
+    files = []
+    with tempfile.TemporaryDirectory() as td:
+        for name, body in (("a.txt", raw[17]), ("b.md", "# Title\n\nBody [1] text (Roe 2001)."), ("c.markdown", raw[18]), ("empty.txt", "  \n ")):
+            pth = os.path.join(td, name)
+            with open(pth, "w", encoding="utf-8") as fh:
+                fh.write(body)
+            files.append({"name": name, "body": body, "pages": [list(p) for p in dp.process_file(pth)]})
+    sect_inputs = [
+        "# Intro\nhello\nworld\n## Methods\nwe did\n\n### Deep\nthings",
+        "preamble line\nAbstract\nthis is it\nRelated Work:\nstuff here\n2. Experiments\nnumbers\n3 Results\nmore",
+        "Introduction\n\nfirst\nsecond\nlowercase header\nNot A header because 1 digit\nConclusion\n",
+        "", "only text without headers", "Header Only", "# A\n# B\nbody of b",
+    ]
+    sections = [{"input": t, "sections": m.DocumentProcessor.extract_sections(dp, t)} for t in sect_inputs]   # via the class: the
+    # instance attribute of the same name (the config flag, :31) shadows the method on instances
+    with open(os.path.join(OUT, "clean_text.json"), "w") as fh:
+        json.dump({"clean": cases, "files": files, "sections": sections}, fh, ensure_ascii=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    gen_clean_text()
     CR = load_reference_retriever()
     with open(os.path.join(OUT, "retrieve_cases.json"), "w") as fh:
         json.dump(gen_retrieve_cases(CR), fh)

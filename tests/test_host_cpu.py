@@ -339,3 +339,30 @@ def test_unsupported_pooling_mode_raises(tmp_path):
     _json.dump({"pooling_mode_max_tokens": True}, open(os.path.join(d, "1_Pooling", "config.json"), "w"))
     with pytest.raises(NotImplementedError):
         _load_local_dir(d)
+
+
+# ---- document processor pinned to the reference's own outputs (f3) ------------------------------------------
+def test_document_processor_matches_reference_goldens(tmp_path):
+    """tests/golden/clean_text.json was produced by running /root/reference/rag/document_processing.py:129-217
+    (oracle/make_golden.py gen_clean_text); the product class must agree bit for bit."""
+    from rag.document_processing import DocumentProcessor
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clean_text.json")) as fh:
+        g = json.load(fh)
+    assert len(g["clean"]) >= 150
+    for case in g["clean"]:
+        dp = DocumentProcessor(dict(case["config"]))
+        assert dp._clean_text(case["input"]) == case["clean"], case
+        assert dp.process_string(case["input"]) == case["process_string"]
+    dp = DocumentProcessor({})
+    for f in g["files"]:
+        pth = tmp_path / f["name"]
+        pth.write_text(f["body"], encoding="utf-8")
+        assert [list(p) for p in dp.process_file(str(pth))] == f["pages"], f["name"]
+    for case in g["sections"]:
+        assert DocumentProcessor.extract_sections(dp, case["input"]) == case["sections"], case["input"]
+    assert dp.extract_sections is False                      # the flag shadows the method on instances, as in the reference
+    with pytest.raises(FileNotFoundError):
+        dp.process_file(str(tmp_path / "missing.txt"))
+    (tmp_path / "x.docx").write_text("x")
+    with pytest.raises(ValueError):
+        dp.process_file(str(tmp_path / "x.docx"))
