@@ -120,8 +120,13 @@ class HipEncoder:
         # the same tensors in the order torch.ops.crs.encoder_forward takes them (csrc/torch_ops.cpp)
         self._wlist = self._keep[-5:] + self._keep[:-5]     # embeddings first, then 12 tensors per layer
         assert len(self._wlist) == 5 + 12 * shape.layers
-        self._desc_list = [shape.vocab_size, shape.hidden, shape.layers, shape.heads, shape.ffn, shape.max_pos,
-                           POOL_CLS if shape.pooling == "cls" else POOL_MEAN]
+
+    @property
+    def _desc_list(self):
+        """crs_encoder_desc as the int list torch.ops.crs.encoder_forward takes (read from `desc`, so tests that
+        switch `desc.pooling` are honoured)."""
+        d = self.desc
+        return [d.vocab_size, d.hidden, d.layers, d.heads, d.ffn, d.max_pos, d.pooling]
 
     def workspace_bytes(self, batch: int, seq: int) -> int:
         out = c_size_t(0)
@@ -159,6 +164,6 @@ class HipEncoder:
                 raise ValueError("q16_out must be fp16 [batch, padded_dim]")
         hidden = torch.empty((b, s, self.shape.hidden), dtype=torch.float32, device=self.device) if return_hidden else None
         with nat._translate():
-            nat.ops().encoder_forward(ids, lens, self._wlist, self._desc_list, float(self.shape.ln_eps), ws, out, q16_out,
+            nat.ops().encoder_forward(ids, lens, self._wlist, self._desc_list, float(self.desc.ln_eps), ws, out, q16_out,
                                       int(slab_type), bool(normalize), hidden)
         return (out, hidden) if return_hidden else out

@@ -1,67 +1,61 @@
-"""Row sharding of the slab across ranks + the one exchange step of a sharded search.
+"""Row sharding of the slab + the one exchange step of a sharded search.
 
-The reference is single-process; this is the new multi-GPU layer of
-section 8(e): contiguous row shards per rank, each rank scans its own shard, ONE all-gather of the
-per-shard (score, id) lists (KiB-sized, latency-bound) and a k-way merge on every rank.  The
-collective and the merge are injected so the same code runs under RCCL with the HIP merge kernel
-(product) and under gloo with a CPU merge (tests/test_shard_cpu.py).
+The reference is single-process; this is the new multi-GPU layer of section 8(e):
+contiguous row shards, each shard scanned where it lives, ONE all-gather of the per-shard results and a k-way
+merge on every rank.  Two drivers share it:
+  * SPMD (one process per GPU, torch.distributed over RCCL): ``VectorStore({"sharded": True})``, bench.py;
+  * one process driving N devices (so RAGPipeline stays one object): ``VectorStore({"num_gpus": N})``.
+Ids on the wire are GLOBAL sidecar rows (the row of the ids / documents / metadatas lists, identical on every
+rank), so the merged order (score desc, row asc) is the single-GPU order whatever the sharding.
+The wire block layout is the C ABI's (include/crs_hip.h: [ids int64 [nq, k] | scores fp32 [nq, k] | pad to 8]).
 """
 from __future__ import annotations
 
 from typing import Callable, List, Tuple
 
-RANK_SHIFT = 40          # ids on the wire = (rank << 40) | local_row  -> order = (rank, local row)
-LOCAL_MASK = (1 << RANK_SHIFT) - 1
-
 
 def shard_slice(n_items: int, world: int, rank: int) -> Tuple[int, int]:
-    """Rows [lo, hi) of an n_items batch that `rank` keeps (contiguous, ceil-sized shards)."""
+    """Rows [lo, hi) of an n_items batch that shard `rank` keeps (contiguous, ceil-sized shards)."""
     per = -(-n_items // world) if n_items else 0
     return min(rank * per, n_items), min((rank + 1) * per, n_items)
 
 
-class ShardMap:
-    """Maps (rank, local slab row) back to the row of the host sidecars (ids / documents / metadata),
-    across any number of sharded add() batches."""
-
-    def __init__(self, world: int):
-        self.world = world
-        self.batches: List[Tuple[int, int]] = []   # (sidecar start row, batch rows)
-
-    def add_batch(self, start_row: int, n_items: int) -> None:
-        self.batches.append((start_row, n_items))
-
-    def global_row(self, rank: int, local_row: int) -> int:
-        for start, n in self.batches:
-            lo, hi = shard_slice(n, self.world, rank)
-            if local_row < hi - lo:
-                return start + lo + local_row
-            local_row -= hi - lo
-        raise IndexError((rank, local_row))
-
-    def clear(self) -> None:
-        self.batches.clear()
+def batch_slices(n_items: int, world: int) -> List[Tuple[int, int]]:
+    return [shard_slice(n_items, world, r) for r in range(world)]
 
 
-def tag(ids, rank: int):
-    """local rows (torch int64, -1 = empty) -> wire ids carrying the rank in the high bits."""
+def wire_layout(nq: int, k: int) -> Tuple[int, int]:
+    """(block bytes, byte offset of the scores) -- the Python statement of crs_wire_bytes / crs_wire_scores_offset
+    (tests hold the two to equality)."""
+    ids_bytes = nq * k * 8
+    return ids_bytes + (nq * k * 4 + 7) // 8 * 8, ids_bytes
+
+
+def pack_wire(scores, ids):
+    """scores fp32 [nq, k], ids int64 [nq, k] (torch, any device) -> uint8 wire block (a copy; the HIP path writes the
+    block in place through rag._native.WireBlock instead)."""
     import torch
-    return torch.where(ids >= 0, ids + (rank << RANK_SHIFT), ids)
+    nq, k = scores.shape
+    nbytes, off = wire_layout(nq, k)
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=scores.device)
+    buf[:off].view(torch.int64).copy_(ids.reshape(-1))
+    buf[off:off + nq * k * 4].view(torch.float32).copy_(scores.reshape(-1))
+    return buf
 
 
-def untag(wire_id: int) -> Tuple[int, int]:
-    return wire_id >> RANK_SHIFT, wire_id & LOCAL_MASK
-
-
-def allgather_merge(dist, scores, wire_ids, k: int, merge_fn: Callable):
-    """scores fp32 [nq, k], wire_ids int64 [nq, k] of THIS rank -> merged top-k over all ranks.
-    merge_fn(gathered_scores [W, nq, k], gathered_ids [W, nq, k], k) -> (scores, ids)."""
+def unpack_wire(gathered, nlists: int, nq: int, k: int):
+    """uint8 [nlists * block] -> (scores fp32 [nlists, nq, k], ids int64 [nlists, nq, k]) (copies)."""
     import torch
-    w = dist.get_world_size()
-    nq, kk = scores.shape
-    # flat [W * nq, k] output (concatenation along dim 0) is the form every backend accepts
-    gs = torch.empty((w * nq, kk), dtype=scores.dtype, device=scores.device)
-    gi = torch.empty((w * nq, kk), dtype=wire_ids.dtype, device=wire_ids.device)
-    dist.all_gather_into_tensor(gs, scores.contiguous())
-    dist.all_gather_into_tensor(gi, wire_ids.contiguous())
-    return merge_fn(gs.view(w, nq, kk), gi.view(w, nq, kk), k)
+    nbytes, off = wire_layout(nq, k)
+    blocks = gathered.view(nlists, nbytes)
+    ids = torch.stack([blocks[g, :off].clone().view(torch.int64).view(nq, k) for g in range(nlists)])
+    scores = torch.stack([blocks[g, off:off + nq * k * 4].clone().view(torch.float32).view(nq, k) for g in range(nlists)])
+    return scores, ids
+
+
+def allgather_merge(dist, block_buf, gathered, nq: int, k_in: int, k_out: int, merge_fn: Callable):
+    """THE exchange of a sharded search: one all-gather of this rank's wire block, then the k-way merge.
+    block_buf uint8 [block bytes]; gathered uint8 [world * block bytes] (reusable scratch);
+    merge_fn(gathered, nlists, nq, k_in, k_out) -> (scores [nq, k_out], ids [nq, k_out])."""
+    dist.all_gather_into_tensor(gathered, block_buf)
+    return merge_fn(gathered, dist.get_world_size(), nq, k_in, k_out)

@@ -213,5 +213,9 @@ class EmbeddingModel:
     def embed_chunks(self, chunks: List[Chunk], show_progress: bool = True) -> np.ndarray:
         return self.embed([chunk.text for chunk in chunks], show_progress=show_progress)
 
+    def embed_chunks_device(self, chunks: List[Chunk], show_progress: bool = True):
+        """embed_chunks without leaving the device (additive): cuda fp32 [n, d] for VectorStore.create_index."""
+        return self.embed_device([chunk.text for chunk in chunks])
+
     def get_dimension(self) -> int:
         return self.dimension

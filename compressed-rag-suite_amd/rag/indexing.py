@@ -2,18 +2,25 @@
 
 Drop-in for the reference's ChromaDB-backed ``VectorStore`` (/root/reference/rag/indexing.py:14-211):
 same constructor config keys, same method names, argument meaning, return shapes and exceptions.
-What changed underneath: ``collection.add`` -> one ``crs_slab_append_f32`` launch per batch (rows are
+What changed underneath: ``collection.add`` -> one ``crs::slab_append`` launch per batch (rows are
 L2-normalised, cast to fp16 or int8+scale and appended to a device slab); ``collection.query`` ->
-``crs_cosine_topk`` (exact brute-force scan + top-k, include/crs_hip.h).  Documents, ids and
-metadata stay on the host, indexed by row.
+``crs::cosine_topk`` (exact brute-force scan + top-k; include/crs_hip.h, csrc/torch_ops.cpp).  Documents,
+ids and metadata stay on the host, indexed by row.
 
-New, additive surface: ``search_batch`` (many queries per launch), ``add_embeddings_device``
-(zero-copy append of encoder output), optional ``index_dtype`` / ``refine_fp32`` config keys that
-default so an unmodified reference config.json works.  With ``torch.distributed`` initialised and
-``sharded=True`` each rank keeps a contiguous row shard and searches are merged with one RCCL
-all-gather.
+New, additive surface (all keys absent from the reference config.json default so that it works unmodified):
+  ``search_batch``            many queries per launch
+  ``index_dtype``             'fp16' (default) | 'int8' (per-row scale)
+  ``refine_fp32``             keep an fp32 shadow of the rows, over-fetch ``refine_overfetch`` (16) candidates and re-rank
+                              them in fp32 (crs::refine_f32): the ranking an fp32 store such as the reference's returns
+  ``num_gpus`` / ``devices``  ONE process driving N devices: contiguous row shards, per-device scans, partial lists
+                              copied to the first device and merged there -- RAGPipeline stays one object
+  ``sharded``                 SPMD (one process per GPU, torch.distributed): each rank keeps a row shard; ONE RCCL
+                              all-gather of the per-shard wire blocks + merge on every rank
+``where`` / ``where_document`` filters work on every layout (the sidecars are replicated; each shard scans the
+allowed rows it owns).  ``top_k`` is unlimited as in the reference: above the scan kernels' 64 the shard is
+scored by the library's GEMM kernel and selected with a device sort.
 
-There is no CPU fallback: without a GPU or without libcrs_hip.so every search raises.
+There is no CPU fallback: without a GPU or without the native libraries every search raises.
 """
 from __future__ import annotations
 
@@ -33,37 +40,34 @@ logger = logging.getLogger(__name__)
 _EMPTY = {'ids': [[]], 'documents': [[]], 'metadatas': [[]], 'distances': [[]]}
 
 
-class SlabCollection:
-    """What ``VectorStore.collection`` exposes (the retriever reads ``.metadata`` and the harness
-    ``.count()``, reference rag/retrieval.py:48-50).  Owns the device slab and the host sidecars."""
+class _Shard:
+    """The rows one device holds: slab (+ scales, + fp32 shadow) and, per local row, the global sidecar row."""
 
-    def __init__(self, name: str, index_dtype: str, refine_fp32: bool, device):
-        self.name = name
-        self.metadata = {"hnsw:space": "cosine"}
-        self.index_dtype = index_dtype
-        self.refine_fp32 = refine_fp32
-        self.device = device
+    def __init__(self, index_dtype: str, refine_fp32: bool, device):
+        self.index_dtype, self.refine_fp32, self.device = index_dtype, refine_fp32, device
         self.dim: Optional[int] = None
         self.pdim: Optional[int] = None
-        self.n = 0                     # rows in this rank's shard
+        self.n = 0
         self.capacity = 0
         self.slab = None               # torch [capacity, pdim] fp16 | int8
         self.scales = None             # torch [capacity] fp32 (int8 only)
         self.shadow = None             # torch [capacity, dim] fp32 (refine_fp32 only)
-        self.ids: List[str] = []
-        self.documents: List[str] = []
-        self.metadatas: List[dict] = []
+        self.rows_global = None        # torch [capacity] int64: sidecar row of each local row
+        self.identity = True           # rows_global[i] == i for every row (single shard, unsharded): no mapping needed
         self._workspace = None
 
     @property
     def slab_type(self) -> int:
         return nat.SLAB_I8 if self.index_dtype == "int8" else nat.SLAB_F16
 
-    def count(self) -> int:
-        return len(self.ids)
+    def _grow(self, old, shape, dtype):
+        import torch
+        new = torch.zeros(shape, dtype=dtype, device=self.device)
+        if old is not None and self.n:
+            new[: self.n].copy_(old[: self.n])
+        return new
 
-    # -- storage -------------------------------------------------------------------------------
-    def _reserve(self, rows: int, dim: int):
+    def reserve(self, rows: int, dim: int):
         import torch
         if self.dim is None:
             self.dim, self.pdim = dim, nat.padded_dim(dim, self.slab_type)
@@ -72,36 +76,85 @@ class SlabCollection:
         if rows <= self.capacity:
             return
         cap = max(rows, int(self.capacity * 1.5) + 1024)
-        dt = torch.int8 if self.slab_type == nat.SLAB_I8 else torch.float16
-        new = torch.zeros((cap, self.pdim), dtype=dt, device=self.device)
-        if self.slab is not None and self.n:
-            new[: self.n].copy_(self.slab[: self.n])
-        self.slab = new
+        self.slab = self._grow(self.slab, (cap, self.pdim), torch.int8 if self.slab_type == nat.SLAB_I8 else torch.float16)
         if self.slab_type == nat.SLAB_I8:
-            ns = torch.zeros(cap, dtype=torch.float32, device=self.device)
-            if self.scales is not None and self.n:
-                ns[: self.n].copy_(self.scales[: self.n])
-            self.scales = ns
+            self.scales = self._grow(self.scales, (cap,), torch.float32)
         if self.refine_fp32:
-            nsh = torch.zeros((cap, self.dim), dtype=torch.float32, device=self.device)
-            if self.shadow is not None and self.n:
-                nsh[: self.n].copy_(self.shadow[: self.n])
-            self.shadow = nsh
+            self.shadow = self._grow(self.shadow, (cap, self.dim), torch.float32)
+        self.rows_global = self._grow(self.rows_global, (cap,), torch.int64)
         self.capacity = cap
 
-    def append_device(self, emb):
-        """emb: cuda fp32 [m, dim] (contiguous).  Appends m rows to the slab."""
+    def append(self, emb, first_global_row: int):
+        """emb: fp32 [m, dim] on this device (contiguous) -> m more rows; they are sidecar rows first_global_row.."""
+        import torch
         m, dim = emb.shape
-        self._reserve(self.n + m, dim)
-        nat.slab_append_f32(emb, self.slab, self.n, self.slab_type, scales=self.scales, shadow=self.shadow)
+        self.reserve(self.n + m, dim)
+        if m == 0:
+            return
+        with torch.cuda.device(self.device):
+            nat.slab_append_f32(emb, self.slab, self.n, self.slab_type, scales=self.scales, shadow=self.shadow)
+            self.rows_global[self.n: self.n + m] = torch.arange(first_global_row, first_global_row + m, device=self.device)
+        if first_global_row != self.n:
+            self.identity = False
         self.n += m
 
-    def workspace(self, nq: int, k: int):
+    def workspace(self, nq: int, k: int, n_rows: int):
         import torch
-        need = nat.scan_workspace_bytes(nq, self.dim, k, max(self.n, 1))
+        need = nat.scan_workspace_bytes(nq, self.dim, k, max(n_rows, 1))
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
+
+
+class SlabCollection:
+    """What ``VectorStore.collection`` exposes (the retriever reads ``.metadata`` and the harness ``.count()``,
+    reference rag/retrieval.py:48-50).  Owns the per-device shards and the host sidecars."""
+
+    def __init__(self, name: str, index_dtype: str, refine_fp32: bool, devices: Sequence):
+        self.name = name
+        self.metadata = {"hnsw:space": "cosine"}
+        self.index_dtype = index_dtype
+        self.refine_fp32 = refine_fp32
+        self.shards: List[_Shard] = [_Shard(index_dtype, refine_fp32, d) for d in devices]
+        self.ids: List[str] = []
+        self.documents: List[str] = []
+        self.metadatas: List[dict] = []
+
+    @property
+    def slab_type(self) -> int:
+        return nat.SLAB_I8 if self.index_dtype == "int8" else nat.SLAB_F16
+
+    # first-shard views (single-device stores: the whole index)
+    @property
+    def device(self):
+        return self.shards[0].device
+
+    @property
+    def dim(self):
+        return self.shards[0].dim
+
+    @property
+    def pdim(self):
+        return self.shards[0].pdim
+
+    @property
+    def n(self) -> int:
+        return sum(s.n for s in self.shards)
+
+    @property
+    def slab(self):
+        return self.shards[0].slab
+
+    @property
+    def scales(self):
+        return self.shards[0].scales
+
+    @property
+    def shadow(self):
+        return self.shards[0].shadow
+
+    def count(self) -> int:
+        return len(self.ids)
 
 
 class VectorStore:
@@ -115,27 +168,45 @@ class VectorStore:
         if self.index_dtype not in ('fp16', 'int8'):
             raise ValueError(f"index_dtype must be 'fp16' or 'int8', got {self.index_dtype!r}")
         self.refine_fp32 = bool(config.get('refine_fp32', False))
-        self.refine_factor = int(config.get('refine_factor', 4))
+        self.refine_overfetch = int(config.get('refine_overfetch', 16))
         self.sharded = bool(config.get('sharded', False))
         self._device = config.get('device', None)
+        self._devices_cfg = config.get('devices', None)
+        self.num_gpus = int(config.get('num_gpus', 0) or 0)
+        if self.sharded and (self.num_gpus > 1 or self._devices_cfg):
+            raise ValueError("'sharded' (one process per GPU) and 'num_gpus'/'devices' (one process, N devices) are exclusive")
+        if self.sharded and self.persist_directory:
+            raise NotImplementedError("persist_directory is not supported with sharded=True (each rank holds only its rows); "
+                                      "use num_gpus for a persisted multi-GPU store")
         self.client = self  # the reference keeps a chromadb client here; nothing else reads it
         self.collection: Optional[SlabCollection] = None
-        self._shard_map: Optional[_shard.ShardMap] = None
+        self._wire = {}     # (nq, k) -> WireBlock (SPMD exchange buffers)
         self._initialize_collection()
 
     # -- helpers -------------------------------------------------------------------------------
-    def _torch_device(self):
+    def _torch_devices(self):
         import torch
         nat.require_gpu()
+        if self._devices_cfg:
+            return [torch.device(d) for d in self._devices_cfg]
+        if self.num_gpus > 1:
+            have = torch.cuda.device_count()
+            if self.num_gpus > have:
+                raise nat.NativeError(f"num_gpus={self.num_gpus} but only {have} device(s) are visible")
+            return [torch.device("cuda", g) for g in range(self.num_gpus)]
         if self._device is not None and str(self._device).startswith("cuda"):
-            return torch.device(self._device)
-        return torch.device("cuda", torch.cuda.current_device())
+            d = torch.device(self._device)
+            return [d if d.index is not None else torch.device("cuda", torch.cuda.current_device())]
+        return [torch.device("cuda", torch.cuda.current_device())]
 
     def _dist(self):
         if not self.sharded:
             return None
         import torch.distributed as dist
         return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+
+    def _new_collection(self) -> SlabCollection:
+        return SlabCollection(self.collection_name, self.index_dtype, self.refine_fp32, self._torch_devices())
 
     def _persist_paths(self):
         base = os.path.join(self.persist_directory, self.collection_name)
@@ -150,48 +221,66 @@ class VectorStore:
         if not (os.path.exists(slab_path) and os.path.exists(docs_path)):
             logger.info(f"Collection '{self.collection_name}' will be created on first add")
             return
+        import torch
         try:
-            import torch
             z = np.load(slab_path, allow_pickle=False)
             with open(docs_path) as fh:
                 side = json.load(fh)
-            col = SlabCollection(self.collection_name, str(z["index_dtype"]), self.refine_fp32, self._torch_device())
-            n, dim = int(z["n"]), int(z["dim"])
-            col._reserve(n, dim)
-            col.slab[:n].copy_(torch.from_numpy(z["slab"]))
-            if col.slab_type == nat.SLAB_I8:
-                col.scales[:n].copy_(torch.from_numpy(z["scales"]))
-            if self.refine_fp32 and "shadow" in z.files:
-                col.shadow[:n].copy_(torch.from_numpy(z["shadow"]))
-            elif self.refine_fp32:
-                col.refine_fp32 = False
-                logger.warning("persisted collection has no fp32 shadow; refine_fp32 disabled")
-            col.n = n
-            col.ids, col.documents, col.metadatas = side["ids"], side["documents"], side["metadatas"]
-            self.index_dtype = col.index_dtype
-            self.collection = col
-            logger.info(f"Loaded existing collection: {self.collection_name} ({col.count()} rows)")
-        except nat.NativeError:
-            raise
-        except Exception as e:  # unreadable files behave like "no collection yet"
-            logger.warning(f"Could not load persisted collection: {e}")
+            n, dim, dtype = int(z["n"]), int(z["dim"]), str(z["index_dtype"])
+            rows = {"slab": z["slab"], "scales": z["scales"] if dtype == "int8" else None,
+                    "shadow": z["shadow"] if "shadow" in z.files else None}
+            if len(side["ids"]) != n or rows["slab"].shape[0] != n:
+                raise ValueError(f"slab holds {rows['slab'].shape[0]} rows, sidecar {len(side['ids'])}, header {n}")
+        except Exception as e:
+            # a truncated / foreign file must not silently become an empty store that the next add overwrites
+            raise RuntimeError(f"persisted collection '{self.collection_name}' under {self.persist_directory} is unreadable: {e}") from e
+        self.index_dtype = dtype
+        refine = self.refine_fp32 and rows["shadow"] is not None
+        if self.refine_fp32 and not refine:
+            logger.warning("persisted collection has no fp32 shadow; refine_fp32 disabled")
+        col = SlabCollection(self.collection_name, dtype, refine, self._torch_devices())
+        for g, (lo, hi) in enumerate(_shard.batch_slices(n, len(col.shards))):
+            sh = col.shards[g]
+            sh.reserve(hi - lo, dim)
+            if hi > lo:
+                sh.slab[: hi - lo].copy_(torch.from_numpy(rows["slab"][lo:hi]))
+                if rows["scales"] is not None:
+                    sh.scales[: hi - lo].copy_(torch.from_numpy(rows["scales"][lo:hi]))
+                if refine:
+                    sh.shadow[: hi - lo].copy_(torch.from_numpy(rows["shadow"][lo:hi]))
+                sh.rows_global[: hi - lo] = torch.arange(lo, hi, device=sh.device)
+            sh.n = hi - lo
+            sh.identity = (lo == 0)
+        col.ids, col.documents, col.metadatas = side["ids"], side["documents"], side["metadatas"]
+        self.collection = col
+        logger.info(f"Loaded existing collection: {self.collection_name} ({col.count()} rows)")
 
     def persist(self):
-        """Write the slab + sidecars under persist_directory (the PersistentClient analogue)."""
+        """Write the slab + sidecars under persist_directory (the PersistentClient analogue): rows in sidecar order
+        whatever the device layout, each file written to a temporary name and moved into place."""
         if not self.persist_directory or self.collection is None:
             return
+        import torch
         os.makedirs(self.persist_directory, exist_ok=True)
         col = self.collection
         slab_path, docs_path = self._persist_paths()
-        arrays = {"slab": col.slab[: col.n].cpu().numpy(), "n": np.int64(col.n), "dim": np.int64(col.dim),
-                  "index_dtype": np.str_(col.index_dtype)}
+        order = torch.cat([s.rows_global[: s.n].cpu() for s in col.shards]).argsort().numpy()
+
+        def gather(name):
+            return torch.cat([getattr(s, name)[: s.n].cpu() for s in col.shards]).numpy()[order]
+
+        arrays = {"slab": gather("slab"), "n": np.int64(col.n), "dim": np.int64(col.dim), "index_dtype": np.str_(col.index_dtype)}
         if col.slab_type == nat.SLAB_I8:
-            arrays["scales"] = col.scales[: col.n].cpu().numpy()
+            arrays["scales"] = gather("scales")
         if col.refine_fp32:
-            arrays["shadow"] = col.shadow[: col.n].cpu().numpy()
-        np.savez(slab_path, **arrays)
-        with open(docs_path, "w") as fh:
+            arrays["shadow"] = gather("shadow")
+        tmp = slab_path + ".tmp.npz"
+        np.savez(tmp, **arrays)
+        os.replace(tmp, slab_path)
+        tmp = docs_path + ".tmp"
+        with open(tmp, "w") as fh:
             json.dump({"ids": col.ids, "documents": col.documents, "metadatas": col.metadatas}, fh)
+        os.replace(tmp, docs_path)
 
     @staticmethod
     def _chunk_metadata(chunk, fields: Sequence[str]) -> dict:
@@ -215,32 +304,28 @@ class VectorStore:
         try:
             import torch
             if self.collection is None:
-                self.collection = SlabCollection(self.collection_name, self.index_dtype, self.refine_fp32,
-                                                 self._torch_device())
+                self.collection = self._new_collection()
                 logger.info(f"Created new collection: {self.collection_name}")
             col = self.collection
             if isinstance(embeddings, torch.Tensor):
-                emb = embeddings.to(device=col.device, dtype=torch.float32).contiguous()
+                emb = embeddings.to(dtype=torch.float32)
             else:
-                emb = torch.from_numpy(np.ascontiguousarray(embeddings, dtype=np.float32)).to(col.device)
+                emb = torch.from_numpy(np.ascontiguousarray(embeddings, dtype=np.float32))
             if emb.ndim != 2:
                 raise ValueError(f"embeddings must be 2-D, got shape {tuple(emb.shape)}")
             logger.info(f"Adding {len(chunks)} chunks to index...")
+            start = len(col.ids)
             dist = self._dist()
-            if dist is not None:
-                # contiguous row shards: rank r keeps rows [lo, hi) of this batch on its GPU
-                if self._shard_map is None:
-                    self._shard_map = _shard.ShardMap(dist.get_world_size())
+            if dist is not None:      # SPMD: this rank keeps rows [lo, hi) of the batch on its GPU
                 lo, hi = _shard.shard_slice(len(chunks), dist.get_world_size(), dist.get_rank())
-                self._shard_map.add_batch(len(col.ids), len(chunks))
-                if hi > lo:
-                    col.append_device(emb[lo:hi].contiguous())
-            else:
-                col.append_device(emb)
+                col.shards[0].append(emb[lo:hi].to(col.shards[0].device).contiguous(), start + lo)
+            else:                     # one process: shard g of the batch goes to device g (one shard: everything)
+                for sh, (lo, hi) in zip(col.shards, _shard.batch_slices(len(chunks), len(col.shards))):
+                    sh.append(emb[lo:hi].to(sh.device).contiguous(), start + lo)
             col.ids.extend(chunk.chunk_id for chunk in chunks)
             col.documents.extend(chunk.text for chunk in chunks)
             col.metadatas.extend(self._chunk_metadata(chunk, fields) for chunk in chunks)
-            if self.persist_directory and dist is None:
+            if self.persist_directory:
                 self.persist()
             logger.info(f"Index created successfully! Total documents: {col.count()}")
         except (ValueError, nat.NativeError):
@@ -250,57 +335,117 @@ class VectorStore:
             raise
 
     # -- search --------------------------------------------------------------------------------
-    def _topk_device(self, q32, top_k: int, allowed_rows=None):
-        """q32: cuda fp32 [nq, dim] -> (scores [nq,k] fp32, rows [nq,k] int64 host-sidecar rows), cuda."""
+    def _search_shard(self, sh: _Shard, q32, top_k: int, allowed_t):
+        """q32: fp32 [nq, dim] on the shard's device -> (scores [nq, top_k], GLOBAL sidecar rows [nq, top_k]) there."""
         import torch
-        col = self.collection
-        dist = self._dist()
         nq = q32.shape[0]
-        q16 = nat.queries_to_f16(q32, col.slab_type)
-        slab, scales, shadow, n = col.slab, col.scales, col.shadow, col.n
-        row_map = None
-        if allowed_rows is not None:   # metadata filter: scan a gathered sub-slab, map rows back
-            row_map = torch.as_tensor(allowed_rows, dtype=torch.int64, device=col.device)
-            slab = col.slab[row_map].contiguous()
-            scales = col.scales[row_map].contiguous() if scales is not None else None
-            shadow = col.shadow[row_map].contiguous() if shadow is not None else None
-            n = int(row_map.numel())
-        k_scan = top_k
-        refine = col.refine_fp32 and shadow is not None
-        if refine:
-            k_scan = min(nat.MAX_K, max(top_k, top_k * self.refine_factor))
-        if n > 0:
-            k_loc = min(k_scan, nat.MAX_K)
-            s, i = nat.cosine_topk(q16, slab, n, col.dim, k_loc, slab_type=col.slab_type, scales=scales,
-                                   workspace=col.workspace(nq, k_loc))
+        slab, scales, shadow, n = sh.slab, sh.scales, sh.shadow, sh.n
+        row_map = None if sh.identity else (sh.rows_global[:n] if n else None)
+        if allowed_t is not None and n:   # metadata filter: scan a gathered sub-slab of the allowed rows this shard owns
+            local = torch.isin(sh.rows_global[:n], allowed_t.to(sh.device)).nonzero().flatten()
+            slab = sh.slab[local].contiguous()
+            scales = sh.scales[local].contiguous() if scales is not None else None
+            shadow = sh.shadow[local].contiguous() if shadow is not None else None
+            row_map, n = sh.rows_global[local], int(local.numel())
+        if n == 0:
+            return (torch.full((nq, top_k), float("-inf"), dtype=torch.float32, device=sh.device),
+                    torch.full((nq, top_k), -1, dtype=torch.int64, device=sh.device))
+        refine = sh.refine_fp32 and shadow is not None
+        if top_k > nat.MAX_K:
+            s, i = self._topk_large(sh, q32, slab, scales, shadow if refine else None, n, top_k)
+        else:
+            q16 = nat.queries_to_f16(q32, sh.slab_type)
+            k_scan = min(nat.MAX_K, max(top_k, self.refine_overfetch)) if refine else top_k
+            s, i = nat.cosine_topk(q16, slab, n, sh.dim, k_scan, slab_type=sh.slab_type, scales=scales,
+                                   workspace=sh.workspace(nq, k_scan, n))
             if refine:
                 qn = torch.nn.functional.normalize(q32, p=2, dim=1, eps=1e-12).contiguous()
-                nat.rescore_f32(qn, shadow, n, 0, s, i)
-            s, i = s[:, :top_k].contiguous(), i[:, :top_k].contiguous()
-        else:
-            s = torch.full((nq, top_k), float("-inf"), dtype=torch.float32, device=col.device)
-            i = torch.full((nq, top_k), -1, dtype=torch.int64, device=col.device)
+                s, i = nat.refine_f32(qn, shadow, n, 0, i, top_k)
         if row_map is not None:
             i = torch.where(i >= 0, row_map[i.clamp(min=0)], i)
-        if dist is not None:
-            # one RCCL all-gather of the per-shard lists, then the k-way merge kernel on every rank;
-            # wire ids carry the rank so the merged order is (score desc, rank asc, local row asc)
-            s, i = _shard.allgather_merge(dist, s, _shard.tag(i, dist.get_rank()), top_k, nat.merge_topk)
-            ih = i.cpu().numpy()
-            rows = np.full(ih.shape, -1, dtype=np.int64)
-            for a in range(ih.shape[0]):
-                for b in range(ih.shape[1]):
-                    if ih[a, b] >= 0:
-                        rows[a, b] = self._shard_map.global_row(*_shard.untag(int(ih[a, b])))
-            i = torch.from_numpy(rows).to(col.device)
+        return s, i
+
+    def _topk_large(self, sh: _Shard, q32, slab, scales, shadow, n: int, top_k: int):
+        """top_k above the scan kernels' limit (the reference accepts any n_results, rag/indexing.py:152-153):
+        all scores of a row block through the library's GEMM kernel (crs_gemm_f16, fp32 out), device top-k per
+        block, final order by two stable sorts (score desc, row asc).  int8 rows are widened per block."""
+        import torch
+        from rag._encoder import gemm_f16
+        q16 = nat.queries_to_f16(q32, nat.SLAB_F16)
+        if q16.shape[1] != slab.shape[1]:            # int8 slabs pad rows to 256 elements
+            q16 = torch.nn.functional.pad(q16, (0, slab.shape[1] - q16.shape[1]))
+        nq = q32.shape[0]
+        best_s = torch.empty((nq, 0), dtype=torch.float32, device=sh.device)
+        best_i = torch.empty((nq, 0), dtype=torch.int64, device=sh.device)
+        block = 1 << 16
+        zero = torch.zeros((nq, min(block, n)), dtype=torch.float32, device=sh.device)
+        for lo in range(0, n, block):
+            hi = min(n, lo + block)
+            if shadow is not None:                   # exact fp32 scores when the store keeps the fp32 rows
+                sc = torch.nn.functional.normalize(q32, p=2, dim=1, eps=1e-12) @ shadow[lo:hi].T
+            else:
+                w = slab[lo:hi] if scales is None else (slab[lo:hi].float() * scales[lo:hi, None]).half()
+                sc = gemm_f16(q16, w.contiguous(), residual=zero[:, : hi - lo].contiguous(), mode=2)
+            ts, ti = sc.topk(min(top_k, hi - lo), dim=1)
+            best_s, best_i = torch.cat([best_s, ts], 1), torch.cat([best_i, ti + lo], 1)
+            if best_s.shape[1] > 4 * top_k:
+                best_s, best_i = self._order(best_s, best_i, top_k)
+        s, i = self._order(best_s, best_i, top_k)
+        if s.shape[1] < top_k:
+            pad = top_k - s.shape[1]
+            s = torch.nn.functional.pad(s, (0, pad), value=float("-inf"))
+            i = torch.nn.functional.pad(i, (0, pad), value=-1)
+        return s, i
+
+    @staticmethod
+    def _order(s, i, k: int):
+        """(score desc, row asc) via two stable sorts; empty slots (row < 0) last; keep k."""
+        import torch
+        big = torch.iinfo(torch.int64).max
+        o = torch.argsort(torch.where(i >= 0, i, big), dim=1, stable=True)
+        s, i = torch.gather(s, 1, o), torch.gather(i, 1, o)
+        o = torch.argsort(torch.where(i >= 0, s, float("-inf")), dim=1, descending=True, stable=True)[:, :k]
+        return torch.gather(s, 1, o), torch.gather(i, 1, o)
+
+    def _topk_device(self, q32, top_k: int, allowed_rows=None):
+        """q32: fp32 [nq, dim] on the first device -> (scores [nq, k] fp32, sidecar rows [nq, k] int64) there."""
+        import torch
+        col = self.collection
+        nq = q32.shape[0]
+        allowed_t = None
+        if allowed_rows is not None:
+            allowed_t = torch.as_tensor(allowed_rows, dtype=torch.int64, device=col.device)
+        parts = []
+        for sh in col.shards:          # launches are asynchronous: the devices scan their shards concurrently
+            with torch.cuda.device(sh.device):
+                q = q32 if q32.device == sh.device else q32.to(sh.device, non_blocking=True)
+                parts.append(self._search_shard(sh, q, top_k, allowed_t))
+        if len(parts) > 1:             # one process, N devices: partial lists to the first device, merge there
+            dev0 = col.device
+            with torch.cuda.device(dev0):
+                gs = torch.stack([s.to(dev0) for s, _ in parts]).contiguous()
+                gi = torch.stack([i.to(dev0) for _, i in parts]).contiguous()
+                s, i = nat.merge_topk(gs, gi, top_k) if top_k <= nat.MAX_K else self._order(
+                    gs.permute(1, 0, 2).reshape(nq, -1), gi.permute(1, 0, 2).reshape(nq, -1), top_k)
+        else:
+            s, i = parts[0]
+        dist = self._dist()
+        if dist is not None:           # SPMD: ONE all-gather of the wire blocks, k-way merge on every rank
+            if top_k > nat.MAX_K:
+                raise ValueError(f"top_k {top_k} > {nat.MAX_K} is not supported on an SPMD-sharded store")
+            key = (nq, top_k, dist.get_world_size())
+            wb = self._wire.get(key)
+            if wb is None:
+                wb = self._wire[key] = nat.WireBlock(nq, top_k, col.device, dist.get_world_size())
+            wb.scores.copy_(s)
+            wb.ids.copy_(i)
+            s, i = _shard.allgather_merge(dist, wb.buf, wb.gathered, nq, top_k, top_k, nat.merge_topk_wire)
         return s, i
 
     def _filter_rows(self, where: Optional[dict], where_document: Optional[dict]):
         if not where and not where_document:
             return None
         col = self.collection
-        if self._dist() is not None:
-            raise NotImplementedError("metadata filters are not supported on a sharded store")
         keep = []
         for row, (meta, doc) in enumerate(zip(col.metadatas, col.documents)):
             ok = True
@@ -355,8 +500,6 @@ class VectorStore:
         if col.count() == 0 or nq == 0:
             return {k: [[] for _ in range(max(nq, 1))] for k in _EMPTY}
         top_k = min(top_k, col.count())
-        if top_k > nat.MAX_K:
-            raise ValueError(f"top_k {top_k} exceeds the scan kernel's limit of {nat.MAX_K}")
         if isinstance(query_embeddings, torch.Tensor):
             q32 = query_embeddings.to(device=col.device, dtype=torch.float32).contiguous()
         else:
@@ -382,7 +525,7 @@ class VectorStore:
         """Delete the collection (frees the slab; removes persisted files)."""
         if self.collection:
             self.collection = None
-            self._shard_map = None
+            self._wire = {}
             if self.persist_directory:
                 for path in self._persist_paths():
                     if os.path.exists(path):
@@ -400,9 +543,11 @@ class VectorStore:
             return {"status": "empty", "count": 0}
         try:
             col = self.collection
+            elem = 1 if col.slab_type == nat.SLAB_I8 else 2
             return {"name": self.collection_name, "count": col.count(), "metadata": col.metadata,
-                    "index_dtype": col.index_dtype, "dimension": col.dim, "rows_on_this_gpu": col.n,
-                    "slab_bytes": int(col.n * (col.pdim or 0) * (1 if col.slab_type == nat.SLAB_I8 else 2))}
+                    "index_dtype": col.index_dtype, "dimension": col.dim, "rows_on_this_gpu": col.shards[0].n,
+                    "rows_per_device": [s.n for s in col.shards],
+                    "slab_bytes": int(sum(s.n for s in col.shards) * (col.pdim or 0) * elem)}
         except Exception as e:
             logger.error(f"Failed to get stats: {e}")
             return {"status": "error", "error": str(e)}

@@ -68,7 +68,11 @@ class RAGPipeline:
         started = time.time()
         chunks = self._chunks_from(documents)
         logger.info(f"Created {len(chunks)} chunks")
-        embeddings = self.embedding_model.embed_chunks(chunks, show_progress=show_progress)
+        if hasattr(self.embedding_model, "embed_chunks_device"):
+            # encoder output stays in HBM: no D2H -> numpy -> H2D round trip between the encoder and the slab append
+            embeddings = self.embedding_model.embed_chunks_device(chunks, show_progress=show_progress)
+        else:
+            embeddings = self.embedding_model.embed_chunks(chunks, show_progress=show_progress)
         self.vector_store.create_index(chunks, embeddings)
         elapsed = time.time() - started
         logger.info(f"Indexing complete in {elapsed:.2f}s")

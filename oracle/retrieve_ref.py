@@ -158,6 +158,11 @@ class StoreRef:
         if where:
             for key, val in where.items():
                 mask &= np.array([m.get(key) == val for m in self.metas])
+        for op, val in (where_document or {}).items():       # chromadb document filters the reference forwards (:174)
+            if op == "$contains":
+                mask &= np.array([val in t for t in self.docs])
+            elif op == "$not_contains":
+                mask &= np.array([val not in t for t in self.docs])
         idx = np.nonzero(mask)[0]
         order = idx[np.lexsort((idx, -cos[idx]))][:top_k]
         return {

@@ -56,6 +56,10 @@ def test_gemm_vs_torch_fp32(cuda, mode, m, n, k):
 @pytest.mark.parametrize("name,cfg,seed,batch,seq", [
     ("tiny", er.TINY, 11, 4, 24), ("minilm", er.MINILM_L6, 12, 3, 32), ("bge", er.BGE_BASE, 13, 2, 16),
     ("minilm-long", er.MINILM_L6, 21, 2, 150), ("tiny-1tok", er.TINY, 22, 3, 5), ("bge-2blk", er.BGE_BASE, 23, 1, 80),
+    # BASELINE's sequence lengths (configs[1-2]: 512-token chunks = 256 after MiniLM's truncation) and the bge
+    # index-build regime (> 4096 tokens: tiled / streaming GEMMs at K = 768 / 3072, transposed attention over 8 key blocks)
+    ("minilm-4x256", er.MINILM_L6, 31, 4, 256), ("bge-2x512", er.BGE_BASE, 32, 2, 512), ("bge-10x512", er.BGE_BASE, 33, 10, 512),
+    ("minilm-20x256", er.MINILM_L6, 34, 20, 256),
 ])
 def test_encoder_matches_oracle(cuda, name, cfg, seed, batch, seq):
     import torch
