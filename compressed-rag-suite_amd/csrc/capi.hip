@@ -42,7 +42,7 @@ struct Plan {
   int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
   int nqb;                                 // query blocks (64 queries each; 32 * wide_nw for the wide kernel)
   int wide_nw;                             // > 0: scan_wide.hip with this many waves per workgroup
-  int wide_ks;                             // 1: scan_wide_ks.hip (768 / 1024-element rows, 128 queries per workgroup)
+  int w1_qg;                               // > 0: scan_w1.hip, this many queries per workgroup (dump selection)
   int i8_tb;                               // 1: scan_i8.hip in a tile-best mode (tb_slots: 0 dump, else chain)
   int tb_nw;                               // > 0: scan_tb.hip with this many waves per workgroup
   int tb_slots;                            //   its chain length (0: dump mode)
@@ -78,18 +78,18 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   // therefore only known once the stream length is: plan for tile-best first, fall back to classic if it has to chain.
   for (int attempt = 0; attempt < 2; ++attempt) {
     const bool allow_tb = attempt == 0 && tb_enabled();
-    p->wide_nw = (allow_tb && slab_type == CRS_SLAB_F16 && k <= 16) ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
-    p->wide_ks = (allow_tb && !p->wide_nw && slab_type == CRS_SLAB_F16 && crs::scan_wide_ks_applies(nq, k, p->pdim)) ? 1 : 0;
+    p->w1_qg = (allow_tb && slab_type == CRS_SLAB_F16) ? crs::scan_w1_queries_per_wg(nq, k, p->pdim) : 0;
+    p->wide_nw = (allow_tb && !p->w1_qg && slab_type == CRS_SLAB_F16 && k <= 16) ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
     p->tb_nw = 0;
-    if (allow_tb && !p->wide_nw && !p->wide_ks && slab_type == CRS_SLAB_F16)
+    if (allow_tb && !p->w1_qg && !p->wide_nw && slab_type == CRS_SLAB_F16)
       p->tb_nw = (nq > 64 && k <= 16 && crs::scan_tb_has_8_waves(p->pdim)) ? 8 : 4;
     p->i8_tb = (allow_tb && slab_type == CRS_SLAB_I8) ? 1 : 0;   // scan_i8.hip's tile-best modes
-    p->tile_rows = p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : p->wide_ks ? 32 : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
+    p->tile_rows = p->w1_qg ? 32 : p->wide_nw ? crs::scan_wide_tile_rows(p->wide_nw, p->pdim) : slab_type == CRS_SLAB_I8 ? crs::scan_i8_tile_rows() : crs::scan_tile_rows(p->pdim);
     p->n_tiles = (int)((n_rows + p->tile_rows - 1) / p->tile_rows);
-    const int cap = cus * (p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim) : p->wide_ks ? 1
+    const int cap = cus * (p->w1_qg ? 1 : p->wide_nw ? crs::scan_wide_wg_per_cu(p->wide_nw, p->pdim)
                            : p->tb_nw ? crs::scan_tb_wg_per_cu(p->pdim, p->tb_nw) : crs::scan_wg_per_cu());
     // all query blocks of a tile stream must be co-resident: streams = resident slots / query blocks
-    const int qpb = p->wide_nw ? 32 * p->wide_nw : p->wide_ks ? 128 : p->tb_nw ? 16 * p->tb_nw : 64;
+    const int qpb = p->w1_qg ? p->w1_qg : p->wide_nw ? 32 * p->wide_nw : p->tb_nw ? 16 * p->tb_nw : 64;
     const int nqb = (nq + qpb - 1) / qpb;
     p->nqb = nqb;
     int streams = cap / nqb;
@@ -100,7 +100,10 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
     p->kp = partial_width(k);
     p->group_best = 0;
     p->tb_slots = 0;
-    if (p->wide_nw || p->wide_ks) {          // register chain of the K best tile representatives per lane
+    if (p->w1_qg) {                          // dump: every tile's representative goes to the partial list
+      p->kp = (p->n_tiles + p->nwg - 1) / p->nwg;
+      p->group_best = 1;
+    } else if (p->wide_nw) {   // register chain of the K best tile representatives per lane
       p->kp = 2 * crs::scan_wide_slots(k);
       p->group_best = 1;
     } else if (p->tb_nw || p->i8_tb) {
@@ -222,8 +225,9 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.k = k;
   a.nwg = p.nwg;
   a.nqb = p.nqb;
-  const int e = p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
-                : p.wide_ks ? crs::scan_launch_wide_ks(a, p.pdim, st)
+  const int e = p.w1_qg ? crs::scan_launch_w1(a, p.pdim, st)
+                : p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
+                
                 : (slab_type == CRS_SLAB_I8) ? crs::scan_launch_i8(a, p.pdim, p.i8_tb ? p.tb_slots : -1, st)
                 : p.tb_nw ? crs::scan_launch_tb(a, p.pdim, p.tb_nw, p.tb_slots, st)
                                : crs::scan_launch_f16(a, p.pdim, p.nwg, st);
@@ -321,8 +325,8 @@ int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type
   const int rc = make_plan(nq, dim, k, n_rows, slab_type, &p);
   if (rc) return rc;
   char name[96];
-  if (p.wide_nw) snprintf(name, sizeof name, "scan_wide_kernel<%d,%d,%d>", p.pdim, p.wide_nw, crs::scan_wide_slots(k));
-  else if (p.wide_ks) snprintf(name, sizeof name, "scan_wide_ks_kernel<%d,%d>", p.pdim, crs::scan_wide_slots(k));
+  if (p.w1_qg) snprintf(name, sizeof name, "scan_w2_kernel<%d> (%d queries/workgroup, dump)", p.pdim, p.w1_qg);
+  else if (p.wide_nw) snprintf(name, sizeof name, "scan_wide_kernel<%d,%d,%d>", p.pdim, p.wide_nw, crs::scan_wide_slots(k));
   else if (p.tb_nw) snprintf(name, sizeof name, "scan_tb_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, p.tb_nw, p.tb_slots);
   else if (slab_type == CRS_SLAB_I8) snprintf(name, sizeof name, "scan_i8_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32, p.i8_tb ? p.tb_slots : -1);
   else snprintf(name, sizeof name, "scan_f16_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);

@@ -50,9 +50,10 @@ int scan_wide_wg_per_cu(int nw, int pdim);
 int scan_wide_slots(int k);
 int scan_wide_tile_rows(int nw, int pdim);
 int scan_launch_wide(const ScanArgs& a, int pdim, int nw, hipStream_t stream);
-// scan_wide_ks.hip: the same for 768 / 1024-element rows (contraction split over the two waves of a SIMD)
-bool scan_wide_ks_applies(int nq, int k, int pdim);
-int scan_launch_wide_ks(const ScanArgs& a, int pdim, hipStream_t stream);
+
+// scan_w1.hip: > 64 queries per launch on 768-element fp16 rows, k <= 64: 256 queries per workgroup, dump selection
+int scan_w1_queries_per_wg(int nq, int k, int pdim);   // 0: not applicable; else queries per workgroup (128 or 256)
+int scan_launch_w1(const ScanArgs& a, int pdim, hipStream_t stream);
 
 // merge.hip
 int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,

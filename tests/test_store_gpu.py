@@ -170,7 +170,7 @@ def test_pipeline_end_to_end_vs_oracle(cuda):
 
 @pytest.mark.parametrize("dtype,d", [("fp16", 384), ("fp16", 768), ("int8", 768)])
 def test_large_search_batches_agree_with_single_queries(cuda, dtype, d):
-    """search_batch with more than 64 queries takes the large-batch scan kernels (scan_wide / scan_wide_ks, several
+    """search_batch with more than 64 queries takes the large-batch scan kernels (scan_wide / scan_w1, several
     query blocks for int8): every row of the batch must equal the one-query search of the same vector, and the
     reference-semantics store on the host."""
     store, ref, chunks, emb = _pair(n=3000, d=d, seed=9, index_dtype=dtype)

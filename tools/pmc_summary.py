@@ -21,7 +21,7 @@ for w in ("c2", "c3", "c4", "c5"):
             for r in rows[:26]:
                 r[0] = r[0][:160]
                 wr.writerow(r)
-scan_pat = re.compile(r"crs::.*?(scan_(?:tb|i8|wide|wide_ks|f16|f16_ring)_kernel<[^>]*>)")   # ours only (rocprim has *scan* kernels too)
+scan_pat = re.compile(r"crs::.*?(scan_(?:tb|i8|wide|w2|f16|f16_ring)_kernel<[^>]*>)")   # ours only (rocprim has *scan* kernels too)
 summary = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace --output-format csv -- python3 bench.py "
            "--workload <w> --steps 6 --warmup 1 --streams 1 --no-graph --no-cpu-baseline (tools/make_profiles.sh); per-launch means over the scan "
            "kernel's dispatches (first two skipped); hbm_read_bytes = FETCH_SIZE(KiB) * 1024 * 2 (gfx950: FETCH_SIZE reports half of a wide "
