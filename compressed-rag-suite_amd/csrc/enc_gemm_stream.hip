@@ -21,6 +21,7 @@
 // share an A tile run together and A is fetched from HBM once.  One barrier per tile.
 
 #include "enc.h"
+#include "lds_dma.h"
 
 namespace crs {
 namespace {
@@ -42,14 +43,6 @@ __device__ __forceinline__ float gelu_erf_s(float x) {
   return 0.5f * x * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
 }
 
-template <typename T>
-__device__ __forceinline__ const T* uniform_ptr(const T* p) {
-  const unsigned long long b = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-  return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
-}
-
 template <int K, int MODE>
 __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16* __restrict__ A,
                                                                  const _Float16* __restrict__ W,
@@ -67,7 +60,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, fh = lane >> 5;
   const int n_tiles = (M + TR - 1) / TR;
-  const int n_full = M / TR;
   const int bid = (int)blockIdx.x;
   const int cblk = (nstreams & 7) ? bid % ncb : (bid >> 3) % ncb;
   const int strm = (nstreams & 7) ? bid / ncb : ((bid >> 3) / ncb) * 8 + (bid & 7);
@@ -75,53 +67,36 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
   const bool col_ok = col < N;
 
   // staging geometry (chunk P = j*256 + tid of the tile -> swizzled LDS offset), as in scan.hip
-  int lds_dst[kLoads];
+  // tile transfer: global memory -> LDS directly (global_load_lds_dwordx4, lds_dma.h): LDS position P = j * T + tid
+  // receives chunk swz(P) of the tile (source-side swizzle), no staging registers, no LDS stores.  (Round 1 parked the
+  // tile in VGPRs through inline-asm loads with a separate counted wait -- a register the compiler may copy or spill
+  // before the data has landed; that bug class produced one wrong answer in the scan and is gone from the library.)
+  unsigned src_off[kLoads];
 #pragma unroll
   for (int j = 0; j < kLoads; ++j) {
     const int P = j * kThreads + tid;
     const int r = P / kCpr, c = P % kCpr;
-    lds_dst[j] = (r * kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+    src_off[j] = (unsigned)(r * kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16u;
   }
   const char* a_bytes = reinterpret_cast<const char*>(A);
-  const size_t last_chunk = (size_t)M * (K * 2) - 16;
-  u32x4 st[kLoads];
-  auto load_tile = [&](int tile_) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u);
+  auto dma_tile = [&](int tile_, int buf) {
     const int tile = __builtin_amdgcn_readfirstlane(tile_);
-    if (tile < n_full) {
-      const char* base = uniform_ptr(a_bytes + (size_t)tile * kTileBytes);
-#pragma unroll
-      for (int j = 0; j < kLoads; ++j) {
-        const unsigned off = (unsigned)(j * kThreads + tid) * 16u;
-        u32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-        st[j] = x;
-      }
-    } else {  // ragged last tile / past the end: clamp to the matrix's last 16 bytes
-#pragma unroll
-      for (int j = 0; j < kLoads; ++j) {
-        size_t off = (size_t)tile * kTileBytes + (size_t)(j * kThreads + tid) * 16;
-        off = off > last_chunk ? last_chunk : off;
-        const char* p = a_bytes + off;
-        u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-        st[j] = x;
-      }
-    }
-  };
-  auto park_tile = [&](char* dst) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tile >= n_tiles) return;
+    // only the ragged last tile is shorter than kTileBytes: clamp every lane's offset to its last valid 16 bytes
+    const long long left = ((long long)M - (long long)tile * TR) * (K * 2);
+    const unsigned lim = (unsigned)((left < kTileBytes ? left : kTileBytes) - 16);
+    const char* base = uniform_ptr(a_bytes + (size_t)tile * kTileBytes);
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
-      u32x4 x = st[j];
-      asm volatile("" : "+v"(x));
-      st[j] = x;
+      const unsigned off = src_off[j] < lim ? src_off[j] : lim;
+      lds_dma16(lds_wave + (unsigned)(buf * kTileBytes) + (unsigned)(j * kThreads * 16), off, base);
     }
-#pragma unroll
-    for (int j = 0; j < kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };
 
   int t = strm;
-  load_tile(t);
+  dma_tile(t, 0);
 
   // W fragments of this wave's 32 columns: B[k][n] with n = lane & 31, k = 16 ks + 8 (lane >> 5) + j
   f16x8 wf[kKsteps];
@@ -145,11 +120,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
 #pragma unroll
   for (int m = 0; m < 8; ++m) a_off[m] = fr * (kCpr * 16) + ((((m * 2 + fh) ^ fr) & 15) << 4);
 
-  park_tile(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
   __syncthreads();
   int cur = 0;
   for (; t < n_tiles; t += nstreams) {
-    load_tile(t + nstreams);
+    dma_tile(t + nstreams, cur ^ 1);   // the next tile flies while this one is multiplied (its buffer was read one iteration ago)
     const char* buf = smem + cur * kTileBytes;
     f32x16 acc;
 #pragma unroll
@@ -201,7 +176,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
       }
       __builtin_amdgcn_wave_barrier();
     }
-    park_tile(smem + (cur ^ 1) * kTileBytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (and this tile's stores retired)
     __syncthreads();
     cur ^= 1;
   }
@@ -237,60 +212,42 @@ __global__ __launch_bounds__(kKsThreads, 2) void gemm_stream_ks_kernel(const _Fl
   const int pair = wave & 3, kh = wave >> 2;
   const int fr = lane & 31, fh = lane >> 5;
   const int n_tiles = (M + TR - 1) / TR;
-  const int n_full = M / TR;
   const int bid = (int)blockIdx.x;
   const int cblk = (nstreams & 7) ? bid % ncb : (bid >> 3) % ncb;
   const int strm = (nstreams & 7) ? bid / ncb : ((bid >> 3) / ncb) * 8 + (bid & 7);
   const int col = cblk * WN + pair * 32 + fr;
   const bool col_ok = col < N;
 
-  int lds_dst[kLoads];
+  // tile transfer: global memory -> LDS directly (global_load_lds_dwordx4, lds_dma.h): LDS position P = j * T + tid
+  // receives chunk swz(P) of the tile (source-side swizzle), no staging registers, no LDS stores.  (Round 1 parked the
+  // tile in VGPRs through inline-asm loads with a separate counted wait -- a register the compiler may copy or spill
+  // before the data has landed; that bug class produced one wrong answer in the scan and is gone from the library.)
+  unsigned src_off[kLoads];
 #pragma unroll
   for (int j = 0; j < kLoads; ++j) {
     const int P = j * kKsThreads + tid;
     const int r = P / kCpr, c = P % kCpr;
-    lds_dst[j] = (r * kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16;
+    src_off[j] = (unsigned)(r * kCpr + ((c & ~15) | ((c ^ r) & 15))) * 16u;
   }
   const char* a_bytes = reinterpret_cast<const char*>(A);
-  const size_t last_chunk = (size_t)M * (K * 2) - 16;
-  u32x4 st[kLoads];
-  auto load_tile = [&](int tile_) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u);
+  auto dma_tile = [&](int tile_, int buf) {
     const int tile = __builtin_amdgcn_readfirstlane(tile_);
-    if (tile < n_full) {
-      const char* base = uniform_ptr(a_bytes + (size_t)tile * kTileBytes);
-#pragma unroll
-      for (int j = 0; j < kLoads; ++j) {
-        const unsigned off = (unsigned)(j * kKsThreads + tid) * 16u;
-        u32x4 x;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(off), "s"(base) : "memory");
-        st[j] = x;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < kLoads; ++j) {
-        size_t off = (size_t)tile * kTileBytes + (size_t)(j * kKsThreads + tid) * 16;
-        off = off > last_chunk ? last_chunk : off;
-        const char* p = a_bytes + off;
-        u32x4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
-        st[j] = x;
-      }
-    }
-  };
-  auto park_tile = [&](char* dst) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tile >= n_tiles) return;
+    // only the ragged last tile is shorter than kTileBytes: clamp every lane's offset to its last valid 16 bytes
+    const long long left = ((long long)M - (long long)tile * TR) * (K * 2);
+    const unsigned lim = (unsigned)((left < kTileBytes ? left : kTileBytes) - 16);
+    const char* base = uniform_ptr(a_bytes + (size_t)tile * kTileBytes);
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
-      u32x4 x = st[j];
-      asm volatile("" : "+v"(x));
-      st[j] = x;
+      const unsigned off = src_off[j] < lim ? src_off[j] : lim;
+      lds_dma16(lds_wave + (unsigned)(buf * kTileBytes) + (unsigned)(j * kKsThreads * 16), off, base);
     }
-#pragma unroll
-    for (int j = 0; j < kLoads; ++j) *reinterpret_cast<u32x4*>(dst + lds_dst[j]) = st[j];
   };
 
   int t = strm;
-  load_tile(t);
+  dma_tile(t, 0);
   f16x8 wf[kKsteps];   // B[k][n]: n = lane & 31, k = kh DH + 16 ks + 8 (lane >> 5) + j
   {
     const _Float16* wrow = W + (size_t)(col_ok ? col : 0) * K + kh * DH + fh * 8;
@@ -351,14 +308,14 @@ __global__ __launch_bounds__(kKsThreads, 2) void gemm_stream_ks_kernel(const _Fl
     __builtin_amdgcn_wave_barrier();
   };
 
-  park_tile(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
   __syncthreads();
   f32x16 acc_prev;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_prev[r] = 0.f;
   int cur = 0, it = 0;
   for (; t < n_tiles; t += nstreams) {
-    load_tile(t + nstreams);
+    dma_tile(t + nstreams, cur ^ 1);   // the next tile flies while this one is multiplied (its buffer was read one iteration ago)
     const char* buf = smem + cur * kTileBytes;
     if (kh == 0) {
       if (it > 0) finish(acc_prev, t - nstreams, it - 1);
@@ -369,7 +326,7 @@ __global__ __launch_bounds__(kKsThreads, 2) void gemm_stream_ks_kernel(const _Fl
 #pragma unroll
       for (int r = 0; r < 16; ++r) xb[r * 64] = acc[r];
     }
-    park_tile(smem + (cur ^ 1) * kTileBytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (and this tile's stores retired)
     __syncthreads();
     cur ^= 1;
     ++it;
