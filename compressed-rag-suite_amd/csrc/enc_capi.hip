@@ -85,8 +85,8 @@ Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
   Layout l;
   size_t off = 0;
   int split = 1;
-  if (use_panel((int)t, (int)f)) split = (int)f / crs::gemm_panel_chunk((int)f);
-  if (use_panel((int)t, (int)h) && (int)h / crs::gemm_panel_chunk((int)h) > split) split = (int)h / crs::gemm_panel_chunk((int)h);
+  if (use_panel((int)t, (int)f)) split = crs::gemm_panel_splits((int)f);
+  if (use_panel((int)t, (int)h) && crs::gemm_panel_splits((int)h) > split) split = crs::gemm_panel_splits((int)h);
   if (t <= kPanelMaxTokens && crs::ffn_fused_slices((int)h, (int)f) > split) split = crs::ffn_fused_slices((int)h, (int)f);
   l.max_split = split;
   l.x32 = off; off += up256(t * h * 4);
@@ -171,7 +171,12 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   const bool big_ln = T > kPanelMaxTokens && bigln_enabled();
   const bool big_ln_h = big_ln && crs::gemm_rowln2_supported(H, H), big_ln_f = big_ln && crs::gemm_rowln2_supported(H, F);
   const bool rowln_h = fuse_ln && crs::gemm_rowln_supported(H, H), rowln_f = fuse_ln && crs::gemm_rowln_supported(H, F);
-  const bool single_h = panel_h && crs::gemm_panel_chunk(H) == H;   // K = H fits one chunk: fused fp16 epilogues
+  // fp16-epilogue projections (QKV, FFN-up) on the panel kernel: K = H in one chunk, or (CRS_ENC_PANEL_MULTI != 0) walked in
+  // chunks by the workgroup -- bge-base at query-batch sizes, where the row-streaming kernel pays a 196 KB weight prologue
+  // per workgroup for a handful of tiles
+  static int panel_multi = -1;
+  if (panel_multi < 0) { const char* e = getenv("CRS_ENC_PANEL_MULTI"); panel_multi = (e && e[0] == '0') ? 0 : 1; }
+  const bool single_h = T <= kPanelMaxTokens && crs::gemm_panel_chunk(H) != 0 && (crs::gemm_panel_chunk(H) == H || panel_multi);
   // short sequences in the launch-bound regime: QKV projection + attention as one kernel (enc_qkvattn.hip)
   const bool fuse_qa = T <= kPanelMaxTokens && qa_enabled() && crs::qkv_attn_supported(H, d->heads, seq);
   const int ffn_ns = (T <= kPanelMaxTokens && ffn_enabled()) ? crs::ffn_fused_slices(H, F) : 0;
@@ -190,7 +195,7 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
       CRS_TRY(crs::gemm_rowln_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out gemm + layernorm 1");
     } else if (panel_h) {
       CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, st), "out gemm");
-      CRS_TRY(crs::layernorm_launch(y32, H / crs::gemm_panel_chunk(H), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
+      CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(H), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
@@ -208,7 +213,7 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
       CRS_TRY(crs::gemm_rowln_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down gemm + layernorm 2");
     } else if (panel_f) {
       CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, st), "ffn down gemm");
-      CRS_TRY(crs::layernorm_launch(y32, F / crs::gemm_panel_chunk(F), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+      CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(F), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, y32, T, H, F, 2, st), "ffn down gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");

@@ -202,18 +202,28 @@ __global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Flo
                                                                      const _Float16* __restrict__ W,
                                                                      const float* __restrict__ bias,
                                                                      void* __restrict__ out, int M, int N, int K,
-                                                                     int kc) {
+                                                                     int kc, int kin) {
+  // kin > 1: the workgroup's K range (kc * kin) is walked in kin chunks through ONE staging buffer of kc columns --
+  // (TM + 64) * kc * 2 bytes of LDS (48 KB at TM = 128, kc = 128), small enough to sit on a CU beside two scan
+  // workgroups, so that the encoder of the next query batch runs in the matrix/issue slots the HBM-bound scan leaves
+  // idle instead of waiting for a scan boundary ("encoder beside the scan")
   constexpr int kTiles = (TM / 32) * (PN / 32);   // 32 x 32 output tiles: one per wave (8 or 4)
   extern __shared__ __attribute__((aligned(16))) char psm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * PN;
-  const int k0 = blockIdx.z * kc;
   const int cpr = kc >> 3;                 // 16-byte chunks per panel row (multiple of 16)
   char* sa = psm;
   char* sw = psm + TM * cpr * 16;
+  const bool computes = wave < kTiles;   // TM = 64: waves 4..7 only help fetching
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  for (int ci = 0; ci < kin; ++ci) {
+  const int k0 = (blockIdx.z * kin + ci) * kc;
   // ---- one shot: every chunk of both panels (rows past M / N are clamped; their results are never
   // stored).  LDS position P = base + tid walks (row, chunk) incrementally: no divisions in the loop.
   {
@@ -234,12 +244,6 @@ __global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Flo
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const bool computes = wave < kTiles;   // TM = 64: waves 4..7 only help fetching
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int fr = lane & 31, fh = lane >> 5;
   if (computes) {
     const int arow = wm * 32 + fr, wrow = wn * 32 + fr;
     const char* pa = sa + arow * (cpr * 16);
@@ -253,7 +257,8 @@ __global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Flo
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
     }
   }
-  __syncthreads();   // every fragment read done: the panels' LDS becomes the waves' output tiles
+  __syncthreads();   // every fragment read done: the staging buffer may be refilled / becomes the waves' output tiles
+  }
   if (!computes) return;
 
   // Epilogue through a wave-private LDS tile so that a lane stores 16 bytes of one row: 4 (fp32) or 2 (fp16)
@@ -311,9 +316,22 @@ __global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Flo
 
 template <int MODE, int TM>
 int launch_panel_t(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
-                   int splitk, hipStream_t stream) {
+                   int splitk, int kin_req, hipStream_t stream) {
   static bool attr_done = false;
+  // CRS_PANEL_KC=128|256: stage the K range in chunks of that many columns (see the kernel: small-LDS form)
+  static int kc_cap = -1;
+  if (kc_cap < 0) { const char* e = getenv("CRS_PANEL_KC"); kc_cap = e ? atoi(e) : 0; if (kc_cap != 128 && kc_cap != 256 && kc_cap != 384) kc_cap = 0; }
+  // A launch of more workgroups than CUs stages 128 columns at a time: 48 KB of LDS, up to three workgroups resident
+  // per CU, one workgroup's transfers under another's MFMAs (bge-base at query-batch sizes: QKV 288, FFN-up 384, FFN-down
+  // 768 workgroups).  Measured on the bge-base query chain (tools/enc_chain_profile.py): 64 x 16 tokens 945 -> ~800 us per
+  // forward, 16 x 16: 793 -> 584, 256 x 16: 2222 -> 2000.  A single wave of workgroups keeps the one-shot fetch (MiniLM:
+  // every launch <= 192 workgroups; 237 us one-shot against 244-253 in 128-column pieces).  CRS_PANEL_KC forces a size.
+  const long wgs = (long)((n + PN - 1) / PN) * ((m + TM - 1) / TM) * splitk;
+  int kin = kin_req;
+  if (kc_cap && kc > kc_cap && kc % kc_cap == 0) { kin *= kc / kc_cap; kc = kc_cap; }
+  else if (!kc_cap && wgs > 256 && kc > 128 && kc % 128 == 0) { kin *= kc / 128; kc = 128; }
   const int lds = (TM + PN) * kc * 2;
+  const int ep = (MODE == 3 ? 36 * 4 : 40 * 2) * 32 * ((TM / 32) * (PN / 32));   // the epilogue's wave-private tiles re-use the buffer
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<MODE, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (TM + PN) * PKC * 2);
@@ -321,17 +339,17 @@ int launch_panel_t(const _Float16* a, const _Float16* w, const float* bias, void
     attr_done = true;
   }
   dim3 grid((n + PN - 1) / PN, (m + TM - 1) / TM, splitk);
-  hipLaunchKernelGGL((gemm_panel_kernel<MODE, TM>), grid, dim3(kPanelThreads), lds, stream, a, w, bias, out, m, n, k, kc);
+  hipLaunchKernelGGL((gemm_panel_kernel<MODE, TM>), grid, dim3(kPanelThreads), lds > ep ? lds : ep, stream, a, w, bias, out, m, n, k, kc, kin);
   return (int)hipGetLastError();
 }
 
 // 128-row tiles once 64-row tiles would need more than one wave of workgroups on the chip
 template <int MODE>
 int launch_panel(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
-                 int splitk, hipStream_t stream) {
+                 int splitk, int kin, hipStream_t stream) {
   const long wgs64 = (long)((n + PN - 1) / PN) * ((m + 63) / 64) * splitk;
-  if (wgs64 > 256 && m > 64) return launch_panel_t<MODE, 128>(a, w, bias, out, m, n, k, kc, splitk, stream);
-  return launch_panel_t<MODE, 64>(a, w, bias, out, m, n, k, kc, splitk, stream);
+  if (wgs64 > 256 && m > 64) return launch_panel_t<MODE, 128>(a, w, bias, out, m, n, k, kc, splitk, kin, stream);
+  return launch_panel_t<MODE, 64>(a, w, bias, out, m, n, k, kc, splitk, kin, stream);
 }
 
 }  // namespace
@@ -369,16 +387,34 @@ int gemm_panel_chunk(int k) {
   return 0;
 }
 
-// out: mode 0/1 fp16 [M,N] (needs k == kc, i.e. a single chunk); mode 3 fp32 [k/kc][M][N] partials
+// How many fp32 partial slabs a mode-3 launch over contraction length k leaves (the LayerNorm kernel that follows sums
+// them): k / chunk, capped at kPanelMaxSplit -- past that the workgroups walk several chunks each (kernel: kin).  8- and
+// 4-way splits of bge-base's FFN-down (K = 3072) measured the same at 64 queries; 2-way was slower (fewer workgroups).
+constexpr int kPanelMaxSplit = 8;
+int gemm_panel_splits(int k) {
+  const int kc = gemm_panel_chunk(k);
+  if (kc == 0) return 0;
+  static int cap = -1;   // CRS_PANEL_MAX_SPLIT: A/B runs
+  if (cap < 0) { const char* e = getenv("CRS_PANEL_MAX_SPLIT"); cap = e ? atoi(e) : kPanelMaxSplit; if (cap < 1) cap = kPanelMaxSplit; }
+  int s = k / kc;
+  while (s > cap && (s % 2) == 0) s /= 2;
+  return s;
+}
+
+// out: mode 0/1 fp16 [M,N] (any k that is a multiple of the chunk: the workgroup walks the chunks); mode 3 fp32
+// [gemm_panel_splits(k)][M][N] partials
 int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
                       int mode, hipStream_t stream) {
   const int kc = gemm_panel_chunk(k);
   if (kc == 0) return -1;
-  const int splitk = k / kc;
+  const int chunks = k / kc;
   switch (mode) {
-    case 0: return splitk == 1 ? launch_panel<0>(a, w, bias, out, m, n, k, kc, 1, stream) : -1;
-    case 1: return splitk == 1 ? launch_panel<1>(a, w, bias, out, m, n, k, kc, 1, stream) : -1;
-    case 3: return launch_panel<3>(a, w, bias, out, m, n, k, kc, splitk, stream);
+    case 0: return launch_panel<0>(a, w, bias, out, m, n, k, kc, 1, chunks, stream);
+    case 1: return launch_panel<1>(a, w, bias, out, m, n, k, kc, 1, chunks, stream);
+    case 3: {
+      const int splitk = gemm_panel_splits(k);
+      return launch_panel<3>(a, w, bias, out, m, n, k, kc, splitk, chunks / splitk, stream);
+    }
     default: return -1;
   }
 }
