@@ -21,8 +21,9 @@ Workloads (BASELINE.json configs; --workload):
   c2  100k x 384 fp16, 64-query batches (Infinity-Cache resident: a latency case, not an HBM measurement)
   enc-minilm / enc-bge   the index-build side: encoder forward over full-length chunks (tokens/s, MFMA fraction)
 Scaling is STRONG by default: the corpus is fixed and split into N contiguous
-row shards (10M / N rows per GPU), the global query batch is fixed, every rank encodes the whole batch
-(replicated: no query exchange) and scans its shard for all of it.  --scaling weak keeps the round-1
+row shards (10M / N rows per GPU), the global query batch is fixed and every rank scans its shard for all of it.
+The queries are encoded replicated on every rank (N <= 2: one collective per batch) or in shards of Qb / N per rank
+followed by an all-gather of the embeddings (N >= 4: two collectives; --encode).  --scaling weak keeps the round-1
 behaviour (fixed 1.25M-row shard and Qb queries PER RANK; queries are all-gathered first).
 
 The encoder has the architecture BASELINE.json names for the workload (all-MiniLM-L6-v2 for the 384-d
@@ -180,6 +181,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the query batch size")
     ap.add_argument("--rows", type=int, default=0, help="diagnostic: override the corpus rows")
+    ap.add_argument("--encode", default="auto", choices=("auto", "replicated", "sharded"),
+                    help="strong scaling, N > 1: every rank encodes the whole query batch (one collective per batch), or each rank "
+                         "encodes Qb / N queries and the embeddings are all-gathered first (two collectives; the encoder's kernels "
+                         "then cover 1/N of the CUs, so the chains of the in-flight batches run side by side).  auto = sharded "
+                         "from 4 GPUs on (when N divides the batch), replicated below")
+    ap.add_argument("--proxy-encode-shard", type=int, default=0,
+                    help="diagnostic, N = 1: encode only Qb / W queries per batch and tile them W times in place of the all-gather "
+                         "(what one rank of a W-GPU step with --encode sharded executes, minus the collectives)")
     args = ap.parse_args()
 
     import numpy as np
@@ -225,6 +234,15 @@ def main():
     else:
         rows, id_base, nq_all = weak_rows, rank * weak_rows, qb * world
         corpus_rows = weak_rows * world
+    # auto: sharded from 4 GPUs on.  Measured on one GPU as what a rank executes minus the collectives (tools/ab_shard_enc.sh,
+    # --proxy-encode-shard): per batch 0.313 -> 0.261 ms at the 8-GPU shard size, 0.466 -> 0.414 at 4, 0.775 -> 0.749 at 2 --
+    # at 2 GPUs the gain is less than a second collective is expected to cost
+    want_shard = args.encode == "sharded" or (args.encode == "auto" and world >= 4)
+    shard_w = world if (strong and world > 1 and want_shard and qb % world == 0) else 1
+    if world == 1 and args.proxy_encode_shard > 1 and qb % args.proxy_encode_shard == 0:
+        shard_w = args.proxy_encode_shard
+    q_loc = qb // shard_w                      # queries THIS rank encodes per batch
+    gather_q = (world > 1 and (not strong or shard_w > 1)) or (world == 1 and shard_w > 1)
     refine = not args.no_refine
     k_scan = max(k, K_SCAN) if refine else k
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
@@ -253,9 +271,11 @@ def main():
     ids_h = rng.integers(1000, shape.vocab_size, size=(qb, QUERY_TOKENS)).astype(np.int32)
     ids_h[:, 0], ids_h[:, -1] = 101, 102                      # [CLS] ... [SEP], no padding
     mask_h = np.ones((qb, QUERY_TOKENS), dtype=np.int32)
-    ids_d = torch.from_numpy(ids_h).to(dev)
-    lens_d = torch.from_numpy(mask_h.sum(1).astype(np.int32)).to(dev)
-    q32 = enc.forward(ids_d, lens_d).clone()                  # fp32 unit rows [qb, dim]
+    ids_full = torch.from_numpy(ids_h).to(dev)
+    lens_full = torch.from_numpy(mask_h.sum(1).astype(np.int32)).to(dev)
+    q32 = enc.forward(ids_full, lens_full).clone()            # fp32 unit rows [qb, dim] (planting, diagnostics)
+    enc_lo = (rank if world > 1 else 0) * q_loc if shard_w > 1 else 0
+    ids_d, lens_d = ids_full[enc_lo:enc_lo + q_loc].contiguous(), lens_full[enc_lo:enc_lo + q_loc].contiguous()
     # plant a near neighbour of every even query (50 % planted); strong: query 2p lives on rank p % world
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
     mine = [p for p in range(0, qb, 2) if (not strong) or ((p // 2) % world == rank)]
@@ -274,9 +294,9 @@ def main():
     class Ctx:
         """Buffers of one in-flight query batch (a batch touches nothing outside its Ctx + read-only state)."""
         def __init__(self):
-            self.q_out = torch.empty((qb, dim), dtype=torch.float32, device=dev)
-            self.q16 = torch.empty((qb, pd), dtype=torch.float16, device=dev)
-            self.enc_ws = torch.empty(enc.workspace_bytes(qb, QUERY_TOKENS), dtype=torch.uint8, device=dev)
+            self.q_out = torch.empty((q_loc, dim), dtype=torch.float32, device=dev)
+            self.q16 = torch.empty((q_loc, pd), dtype=torch.float16, device=dev)
+            self.enc_ws = torch.empty(enc.workspace_bytes(q_loc, QUERY_TOKENS), dtype=torch.uint8, device=dev)
             self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k_scan, rows), dtype=torch.uint8, device=dev)
             self.cand_s = torch.empty((nq_all, k_scan), dtype=torch.float32, device=dev)
             self.cand_i = torch.empty((nq_all, k_scan), dtype=torch.int64, device=dev)
@@ -285,25 +305,26 @@ def main():
             if world > 1:
                 self.fin_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
                 self.fin_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
-                if not strong:
-                    self.q_all32 = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
-                    self.q_all16 = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
+            if gather_q:
+                self.q_all32 = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
+                self.q_all16 = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
 
     # A batch = device segments with the collectives between them; every segment reads and writes fixed buffers
     # of its Ctx, so each is captured once into a hipGraph and replayed.
     def seg_encode(c):      # token ids -> fp32 embeddings + the scan's fp16 query block
         if args.scan_only:
-            c.q_out.copy_(q32)
+            c.q_out.copy_(q32[enc_lo:enc_lo + q_loc])
             nat.queries_to_f16(c.q_out, slab_type, out=c.q16)
         else:
             enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=slab_type)
 
     def seg_search(c, do_refine=refine):       # all queries of the batch x this rank's shard -> this rank's wire block
-        gathered_q = world > 1 and not strong
-        qa32 = c.q_all32 if gathered_q else c.q_out
-        if gathered_q:
+        qa32 = c.q_all32 if gather_q else c.q_out
+        if gather_q:
+            if world == 1:      # --proxy-encode-shard: the local queries tiled in place of the all-gather
+                c.q_all32.view(shard_w, q_loc, dim).copy_(c.q_out.unsqueeze(0).expand(shard_w, q_loc, dim))
             nat.queries_to_f16(qa32, slab_type, out=c.q_all16)
-        qa16 = c.q_all16 if gathered_q else c.q16
+        qa16 = c.q_all16 if gather_q else c.q16
         if do_refine:
             nat.cosine_topk(qa16, slab, rows, dim, k_scan, slab_type=slab_type, scales=scales, id_base=id_base,
                             workspace=c.ws, out_scores=c.cand_s, out_ids=c.cand_i)
@@ -318,10 +339,10 @@ def main():
     if world == 1:
         segs = [lambda c: (seg_encode(c), seg_search(c))]
         exchanges = []
-    elif strong:            # replicated queries: ONE collective per batch
+    elif strong and not gather_q:   # replicated queries: ONE collective per batch
         segs = [lambda c: (seg_encode(c), seg_search(c)), seg_merge]
         exchanges = [lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)]
-    else:
+    else:                   # queries encoded in shards (or weak scaling: per-rank queries): embeddings gathered first
         segs = [seg_encode, seg_search, seg_merge]
         exchanges = [lambda c: dist.all_gather_into_tensor(c.q_all32, c.q_out),
                      lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)]
@@ -397,11 +418,11 @@ def main():
     # fp32 rows of every shard (fp64 accumulation) -- catches quantisation loss as well as any mix-up of query
     # order, id bases, wire layout or merge.
     def gathered_queries():
-        if world > 1 and not strong:
+        if world > 1 and gather_q:
             qa = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(qa, ctxs[0].q_out.contiguous())
             return qa
-        return ctxs[0].q_out
+        return ctxs[0].q_all32 if gather_q else ctxs[0].q_out
 
     with torch.cuda.stream(streams[0]):
         fin_s, fin_i = batch(ctxs[0])
@@ -425,7 +446,7 @@ def main():
     c0 = ctxs[0]
     with torch.cuda.stream(streams[0]):
         seg_encode(c0)
-        if world > 1 and not strong:
+        if world > 1 and gather_q:
             dist.all_gather_into_tensor(c0.q_all32, c0.q_out)
         if refine:
             seg_search(c0, do_refine=False)
@@ -433,8 +454,12 @@ def main():
             c0.cand_s = torch.empty((nq_all, max(k, K_SCAN)), dtype=torch.float32, device=dev)
             c0.cand_i = torch.empty((nq_all, max(k, K_SCAN)), dtype=torch.int64, device=dev)
             c0.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, max(k, K_SCAN), rows), dtype=torch.uint8, device=dev)
-            qa16 = c0.q_all16 if (world > 1 and not strong) else c0.q16
-            qa32 = c0.q_all32 if (world > 1 and not strong) else c0.q_out
+            qa16 = c0.q_all16 if gather_q else c0.q16
+            qa32 = c0.q_all32 if gather_q else c0.q_out
+            if gather_q:
+                if world == 1:
+                    c0.q_all32.view(shard_w, q_loc, dim).copy_(c0.q_out.unsqueeze(0).expand(shard_w, q_loc, dim))
+                nat.queries_to_f16(qa32, slab_type, out=c0.q_all16)
             nat.cosine_topk(qa16, slab, rows, dim, max(k, K_SCAN), slab_type=slab_type, scales=scales, id_base=id_base,
                             workspace=c0.ws, out_scores=c0.cand_s, out_ids=c0.cand_i)
             nat.refine_f32(qa32, shadow, rows, id_base, c0.cand_i, k, out_scores=c0.wire.scores, out_ids=c0.wire.ids)
@@ -454,13 +479,13 @@ def main():
                      ("scan_only_max_abs_score_err" if refine else "with_fp32_refine_max_abs_score_err"): err_other}
 
     # ---- roofline of the dominant kernel (the scan), hipEvent-timed on the launch stream; the re-rank beside it
-    qa16 = ctxs[0].q_all16 if (world > 1 and not strong) else ctxs[0].q16
+    qa16 = ctxs[0].q_all16 if gather_q else ctxs[0].q16
     ms_total, ms_scan = nat.time_cosine_topk(qa16, slab, rows, dim, k_scan, max(10, min(args.steps, 50)),
                                              slab_type=slab_type, scales=scales)
     ms_refine = None
     if refine:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        qa32 = ctxs[0].q_all32 if (world > 1 and not strong) else ctxs[0].q_out
+        qa32 = ctxs[0].q_all32 if gather_q else ctxs[0].q_out
         e0.record()
         for _ in range(50):
             nat.refine_f32(qa32, shadow, rows, id_base, ctxs[0].cand_i, k, out_scores=ctxs[0].wire.scores, out_ids=ctxs[0].wire.ids)
@@ -552,6 +577,8 @@ def main():
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
                        "query_tokens": QUERY_TOKENS, "hip_graph": use_graph,
                        "collectives_per_batch": len(exchanges),
+                       "query_encode": ("replicated" if not gather_q else ("per-rank queries (weak scaling)" if not strong else
+                                        f"sharded: {q_loc} of {qb} queries per rank" + (" [single-GPU proxy: tiled instead of gathered]" if world == 1 else ""))),
                        "recall_at_10_vs_fp32": recall_report, "check_ok": check_ok,
                        "index_build_s_per_gpu": round(t_build, 3)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -22,21 +22,10 @@ int gemm_panel_splits(int k);   // fp32 partial slabs a mode-3 panel launch leav
 int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
                       int mode, hipStream_t stream);
 
-// enc_rowln.hip: x = LayerNorm(A W^T + bias + residual) in one kernel (query-batch regime; hidden 384 / 768)
-bool gemm_rowln_supported(int hidden, int k);
-int gemm_rowln_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, const float* g,
-                      const float* b, float eps, int m, int hidden, int k, float* x32, _Float16* x16,
-                      hipStream_t stream);
-
 // enc_qkvattn.hip: QKV projection + attention of short sequences (16 / 32 / 64 tokens) in one kernel
 bool qkv_attn_supported(int hidden, int heads, int seq);
 int qkv_attn_launch(const _Float16* x16, const _Float16* w_qkv, const float* b_qkv, const int* lens, _Float16* ctx, int batch,
                     int seq, int hidden, int heads, hipStream_t stream);
-
-// enc_ffn.hip: gelu(x W_up^T + b) W_down^T per 96-wide slice of the intermediate dimension, fp32 partials [ns][T][H]
-int ffn_fused_slices(int hidden, int ffn);   // 0: unsupported shape
-int ffn_fused_launch(const _Float16* x16, const _Float16* w_up, const float* b_up, const _Float16* w_down, float* y32,
-                     int tokens, int hidden, int ffn, hipStream_t stream);
 
 // enc_rowln.hip, pipelined variant for large token counts (index build), hidden = 384
 bool gemm_rowln2_supported(int hidden, int k);

@@ -26,16 +26,6 @@ namespace {
 
 size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
-// The fused feed-forward kernel (enc_ffn.hip) is OFF by default: parity-green, one launch fewer per layer, but
-// measured slower (MiniLM, 64 x 16 tokens: forward 0.295 ms against 0.274 ms; C2 step 0.168 against 0.156 ms):
-// its two operand fetches cannot overlap (W_down's slice re-uses W_up's LDS), and 16 fp32 partials per row
-// cost the LayerNorm 4x the reads of the split-K path.  CRS_ENC_FFN=1 enables it for experiments.
-bool ffn_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CRS_ENC_FFN"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
-
 bool bigln_enabled() {   // CRS_ENC_BIGLN=0: tiled GEMM + separate LayerNorm on the index-build side (A/B runs)
   static int v = -1;
   if (v < 0) { const char* e = getenv("CRS_ENC_BIGLN"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -46,18 +36,6 @@ bool qa_enabled() {   // CRS_ENC_QKVATTN=0: separate QKV GEMM and attention laun
   static int v = -1;
   if (v < 0) { const char* e = getenv("CRS_ENC_QKVATTN"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
-}
-
-// The fused projection + LayerNorm kernel (enc_rowln.hip) is OFF by default: measured on MI355X it is
-// correct but slower than the pair it replaces (MiniLM, 64 x 16 tokens: forward 0.442 ms against 0.292 ms).
-// A workgroup that owns whole rows must stream all of W itself, and a CU ingests only ~50 B/clk through
-// LDS-DMA (~150 cycles of issue per 1 KiB wave-instruction): 1.7 us per 57 KB K-chunk, i.e. 10 us for
-// K = 384 and 41 us for K = 1536, where the split-N / split-K panel GEMM spreads the same bytes over 48-96
-// CUs.  CRS_ENC_ROWLN=1 enables it for experiments.
-int rowln_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CRS_ENC_ROWLN"); v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0; }
-  return v;
 }
 
 struct Layout {
@@ -87,7 +65,6 @@ Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
   int split = 1;
   if (use_panel((int)t, (int)f)) split = crs::gemm_panel_splits((int)f);
   if (use_panel((int)t, (int)h) && crs::gemm_panel_splits((int)h) > split) split = crs::gemm_panel_splits((int)h);
-  if (t <= kPanelMaxTokens && crs::ffn_fused_slices((int)h, (int)f) > split) split = crs::ffn_fused_slices((int)h, (int)f);
   l.max_split = split;
   l.x32 = off; off += up256(t * h * 4);
   l.y32 = off; off += up256(t * h * 4 * split);
@@ -163,14 +140,9 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   CRS_TRY(crs::embed_ln_launch(ids_dev, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, d->ln_eps, T,
                                seq, H, d->vocab_size, x32, x16, st), "embed_ln");
   const bool panel_h = use_panel(T, H), panel_f = use_panel(T, F);
-  // query-batch regime: projection + bias + residual + LayerNorm as one kernel (enc_rowln.hip)
-  // CRS_ENC_ROWLN: 1 = small token counts only (measured slower there), 2 = large token counts only, 3 = both
-  const int rowln_mode = rowln_enabled();
-  const bool fuse_ln = (T <= kPanelMaxTokens) ? (rowln_mode & 1) : (rowln_mode & 2);
   // index-build side (large token counts), hidden = 384: projection + bias + residual + LayerNorm in one pipelined kernel
   const bool big_ln = T > kPanelMaxTokens && bigln_enabled();
   const bool big_ln_h = big_ln && crs::gemm_rowln2_supported(H, H), big_ln_f = big_ln && crs::gemm_rowln2_supported(H, F);
-  const bool rowln_h = fuse_ln && crs::gemm_rowln_supported(H, H), rowln_f = fuse_ln && crs::gemm_rowln_supported(H, F);
   // fp16-epilogue projections (QKV, FFN-up) on the panel kernel: K = H in one chunk, or (CRS_ENC_PANEL_MULTI != 0) walked in
   // chunks by the workgroup -- bge-base at query-batch sizes, where the row-streaming kernel pays a 196 KB weight prologue
   // per workgroup for a handful of tiles
@@ -179,7 +151,6 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   const bool single_h = T <= kPanelMaxTokens && crs::gemm_panel_chunk(H) != 0 && (crs::gemm_panel_chunk(H) == H || panel_multi);
   // short sequences in the launch-bound regime: QKV projection + attention as one kernel (enc_qkvattn.hip)
   const bool fuse_qa = T <= kPanelMaxTokens && qa_enabled() && crs::qkv_attn_supported(H, d->heads, seq);
-  const int ffn_ns = (T <= kPanelMaxTokens && ffn_enabled()) ? crs::ffn_fused_slices(H, F) : 0;
   for (int li = 0; li < d->layers; ++li) {
     const crs_encoder_layer& L = w->layers[li];
     if (fuse_qa) {
@@ -191,8 +162,6 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
     }
     if (big_ln_h) {
       CRS_TRY(crs::gemm_rowln2_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out projection + layernorm 1");
-    } else if (rowln_h) {
-      CRS_TRY(crs::gemm_rowln_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out gemm + layernorm 1");
     } else if (panel_h) {
       CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(H), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
@@ -200,17 +169,10 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
       CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
     }
-    if (ffn_ns) {   // both FFN projections in one launch, F/96 fp32 partials summed by the LayerNorm
-      CRS_TRY(crs::ffn_fused_launch(x16, (const _Float16*)L.w_up, L.b_up, (const _Float16*)L.w_down, y32, T, H, F, st), "ffn");
-      CRS_TRY(crs::layernorm_launch(y32, ffn_ns, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
-      continue;
-    }
     if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_up, L.b_up, ffn, T, F, H, 1, st), "ffn up gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");
     if (big_ln_f) {
       CRS_TRY(crs::gemm_rowln2_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down projection + layernorm 2");
-    } else if (rowln_f) {
-      CRS_TRY(crs::gemm_rowln_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down gemm + layernorm 2");
     } else if (panel_f) {
       CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, st), "ffn down gemm");
       CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(F), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");

@@ -1,31 +1,11 @@
-// enc_rowln.hip -- GEMM + bias + residual + LayerNorm in ONE kernel, for the launch-bound query-batch
-// side of the encoder (a few hundred to a few thousand token rows).
+// enc_rowln.hip -- projection + bias + residual + LayerNorm in ONE pipelined kernel for the index-build side of the
+// encoder (large token counts, hidden = 384): gemm_rowln2_kernel.
 //
 //   x = LayerNorm( A[M, K] W[H, K]^T + bias + residual )      -> x32 (fp32 residual stream), x16 (next GEMM's input)
 //
-// replaces the pair "panel GEMM (split-K fp32 partials) -> layernorm_kernel" after the attention output
-// projection (K = H) and after the FFN down projection (K = F): at 1024 tokens each of those kernels
-// costs 5.5-9 us, almost all of it launch ramp and dependent memory round trips, and the encoder's
-// 44-launch chain -- not any kernel's arithmetic -- bounds the retrieve step.
-//
-// A LayerNorm needs whole rows, so a workgroup owns TM = 64 (H = 384) or 32 (H = 768) FULL output rows:
-//   * 8 waves; wave w accumulates a 32-row x 96-column block (three 32x32 accumulators,
-//     v_mfma_f32_32x32x16_f16) of the TM x H tile over the whole contraction;
-//   * K is walked in chunks of KC = 64 (H = 384) or 32 (H = 768) halves: the A chunk [TM, KC] and the W
-//     chunk [H, KC] (<= 57 KB together) are fetched by LDS-DMA (global_load_lds_dwordx4, nothing staged in
-//     VGPRs) into a double buffer, one barrier per chunk, the next chunk's DMA issued before the current
-//     chunk's MFMAs.  LDS rows are KC halves (128 / 64 bytes); their 16-byte pieces are XOR-swizzled by row
-//     on the SOURCE side (the DMA writes LDS linearly).  Rows 8 apart still share banks (2-way conflict
-//     on a fragment read): 16 reads per chunk and wave, invisible next to the DMA issue;
-//   * epilogue: the accumulators (+ nothing yet) go to an fp32 LDS tile that re-uses the operand buffers;
-//     then every wave normalises rows of it exactly like enc_misc.hip's layernorm_kernel (bias and
-//     residual added in fp32, two-pass statistics, eps inside the sqrt), so the global loads and stores
-//     of the epilogue are row-contiguous.
-// STATUS: parity-green but measured SLOWER than the two launches it replaces and therefore off by default
-// (enc_capi.hip, CRS_ENC_ROWLN=1 to enable): owning whole rows means every workgroup streams all of W, and
-// one CU's LDS-DMA issue rate (~50 B/clk) makes that 10 us at K = 384 and 41 us at K = 1536 on 16 CUs.
-// The contraction is accumulated in one MFMA chain instead of per-384 split-K partials summed later:
-// last-bit differences only (tests: 1 - cos < 2e-4 against the fp32 oracle, unchanged).
+// (Round 1 also kept a small-token variant of this idea, gemm_rowln_kernel, and a fused feed-forward kernel, enc_ffn.hip:
+// both parity-green, both measured SLOWER than the launches they replaced -- a workgroup that owns whole rows streams all
+// of W through one CU -- and both were removed in round 2 instead of staying opt-in; DESIGN.md section 3.4 keeps the numbers.)
 
 #include "enc.h"
 
@@ -47,187 +27,23 @@ __device__ __forceinline__ float wave_sum_rl(float x) {
   return x;
 }
 
-template <int H>
-struct RlCfg {
-  static constexpr int TM = H <= 384 ? 64 : 32;          // rows per workgroup
-  static constexpr int KC = H <= 384 ? 64 : 32;          // halves of K per chunk
-  static constexpr int CPR = KC / 8;                     // 16-byte pieces per LDS row
-  static constexpr int NRB = TM / 32;                    // 32-row blocks
-  static constexpr int NCG = 8 / NRB;                    // column groups (one per wave and row block)
-  static constexpr int CB = (H / 32) / NCG;              // 32-column blocks per wave
-  static constexpr int kRows = TM + H;                   // LDS rows per stage: A rows, then W rows
-  static constexpr int kStageBytes = kRows * KC * 2;
-  static constexpr int kPieces = kRows * CPR;            // 16-byte pieces per stage
-  static constexpr int kInstr = kPieces / 64;            // DMA wave-instructions per stage
-  static constexpr int kPerWave = (kInstr + 7) / 8;
-  static constexpr int kTileStride = H + 4;              // floats; epilogue tile row stride
-  static constexpr int kTileBytes = TM * kTileStride * 4;
-  static constexpr int kLds = (2 * kStageBytes > kTileBytes) ? 2 * kStageBytes : kTileBytes;
-  static_assert(H % 128 == 0 && (H / 32) % NCG == 0, "hidden size must split into 32-column blocks over the waves");
-  static_assert(kPieces % 64 == 0, "a stage must be a whole number of DMA instructions");
-};
-
-template <int H>
-__global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln_kernel(const _Float16* __restrict__ A,
-                                                                  const _Float16* __restrict__ W,
-                                                                  const float* __restrict__ bias,
-                                                                  const float* residual,   // may alias x32
-                                                                  const float* __restrict__ g,
-                                                                  const float* __restrict__ b, float eps, int M,
-                                                                  int K, float* x32, _Float16* __restrict__ x16) {
-  using C = RlCfg<H>;
-  extern __shared__ __attribute__((aligned(16))) char rsm[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * C::TM;
-
-  // ---- DMA geometry: instruction i (this wave's i-th) covers pieces (i * 8 + wave) * 64 + lane
-  const char* src[C::kPerWave];
-  int dst[C::kPerWave];
-#pragma unroll
-  for (int i = 0; i < C::kPerWave; ++i) {
-    const int ins = i * 8 + wave;
-    const int p = ins * 64 + lane;
-    const int row = min(p / C::CPR, C::kRows - 1), cp = p % C::CPR;
-    const int c = cp ^ (row & (C::CPR - 1));
-    const _Float16* base = (row < C::TM) ? A + (size_t)min(m0 + row, M - 1) * K : W + (size_t)(row - C::TM) * K;
-    src[i] = reinterpret_cast<const char*>(base + c * 8);
-    dst[i] = ins * 1024;   // LDS byte offset of the instruction's 1 KiB (lane * 16 added by the hardware)
-  }
-  auto issue = [&](int chunk, int stage) {
-    char* sb = rsm + stage * C::kStageBytes;
-#pragma unroll
-    for (int i = 0; i < C::kPerWave; ++i) {
-      if (i * 8 + wave < C::kInstr)   // wave-uniform
-        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)chunk * (C::KC * 2)), (lptr_t)(sb + dst[i]), 16, 0, 0);
-    }
-  };
-
-  // ---- MFMA geometry
-  const int fr = lane & 31, fh = lane >> 5;
-  const int rb = wave % C::NRB, cg = wave / C::NRB;
-  const int arow = rb * 32 + fr;                          // LDS row of this lane's A fragment
-  int wrow[C::CB];
-#pragma unroll
-  for (int j = 0; j < C::CB; ++j) wrow[j] = C::TM + (cg * C::CB + j) * 32 + fr;
-  f32x16 acc[C::CB];
-#pragma unroll
-  for (int j = 0; j < C::CB; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  const int nchunks = K / C::KC;
-  issue(0, 0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of chunk ch has landed
-    __syncthreads();                                      // everyone's has; everyone is done reading the other stage
-    if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
-    const char* sb = rsm + (ch & 1) * C::kStageBytes;
-#pragma unroll
-    for (int ks = 0; ks < C::KC / 16; ++ks) {
-      const int c = 2 * ks + fh;
-      const f16x8 af = *reinterpret_cast<const f16x8*>(sb + arow * (C::KC * 2) + ((c ^ (arow & (C::CPR - 1))) << 4));
-#pragma unroll
-      for (int j = 0; j < C::CB; ++j) {
-        const f16x8 bf = *reinterpret_cast<const f16x8*>(sb + wrow[j] * (C::KC * 2) + ((c ^ (wrow[j] & (C::CPR - 1))) << 4));
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[j], 0, 0, 0);
-      }
-    }
-  }
-  __syncthreads();   // all fragment reads done: the operand buffers become the fp32 tile
-
-  // ---- accumulators -> LDS tile [TM][H (+4)]
-  float* tile = reinterpret_cast<float*>(rsm);
-#pragma unroll
-  for (int j = 0; j < C::CB; ++j) {
-    const int col = (cg * C::CB + j) * 32 + fr;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      tile[row * C::kTileStride + col] = acc[j][r];
-    }
-  }
-  __syncthreads();
-
-  // ---- row LayerNorm (as layernorm_kernel in enc_misc.hip): wave w takes rows w, w + 8, ...
-  constexpr int PL = H / 64;
-  float gg[PL], bb[PL], bi[PL];
-#pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    const int c = lane + 64 * i;
-    gg[i] = g[c];
-    bb[i] = b[c];
-    bi[i] = bias ? bias[c] : 0.f;
-  }
-  for (int row = wave; row < C::TM; row += 8) {
-    const int gr = m0 + row;
-    if (gr >= M) break;   // wave-uniform
-    float v[PL];
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = (tile[row * C::kTileStride + c] + bi[i]) + residual[(size_t)gr * H + c];
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) s += v[i];
-    const float mean = wave_sum_rl(s) / H;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const float d = v[i] - mean;
-      q += d * d;
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum_rl(q) / H + eps);
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      const float o = (v[i] - mean) * rstd * gg[i] + bb[i];
-      x32[(size_t)gr * H + c] = o;
-      x16[(size_t)gr * H + c] = (_Float16)o;
-    }
-  }
-}
-
-template <int H>
-int launch_rowln(const _Float16* a, const _Float16* w, const float* bias, const float* residual, const float* g,
-                 const float* b, float eps, int m, int k, float* x32, _Float16* x16, hipStream_t stream) {
-  using C = RlCfg<H>;
-  static bool done = false;
-  auto kernel = &gemm_rowln_kernel<H>;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
-    if (e != hipSuccess) return (int)e;
-    done = true;
-  }
-  hipLaunchKernelGGL(kernel, dim3((m + C::TM - 1) / C::TM), dim3(kRlThreads), C::kLds, stream, a, w, bias, residual, g,
-                     b, eps, m, k, x32, x16);
-  return (int)hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// LARGE token counts (index build), H = 384: the same fusion with a pipeline that keeps the CU's DMA port busy.
-// The kernel above pays issue -> round trip -> barrier -> MFMA serially per chunk (1.7 us per 57 KB); with
-// thousands of rows there is no shortage of workgroups, so here a workgroup owns 128 full rows and walks K in
-// chunks of 32 through a FOUR-stage LDS ring, three chunks in flight:
-//   * a stage = A chunk [128, 32] + W chunk [384, 32] = 512 rows of 64 bytes = 32 KB = exactly 32 LDS-DMA
-//     instructions, four per wave -- uniform, so a counted s_waitcnt vmcnt(8) means "chunk ch has landed, the
-//     next two may still be in flight"; 16-byte pieces XOR-swizzled by (row >> 2) & 3 on the source side
-//     (64-byte rows: rows 4 apart share banks);
+// A workgroup owns 128 full rows and walks K in chunks through an LDS ring:
+//   * a stage = A chunk [128, KC] + W chunk [384, KC] = 512 rows; (KC, stages) = (32, 4): 64-byte row pieces, 32 KB per
+//     stage = exactly 32 LDS-DMA instructions, four per wave, three chunks in flight -- uniform, so a counted
+//     s_waitcnt vmcnt(8) means "chunk ch has landed, the next two may still be in flight"; (64, 2), the default: 128-byte
+//     pieces, one chunk in flight; 16-byte pieces XOR-swizzled on the source side;
 //   * per chunk and wave 12 MFMAs (one 32-row block x six 32-column blocks x two k-steps, 7 fragment reads per
-//     6 MFMAs) with the next stage's four DMA instructions issued between them;
+//     6 MFMAs) with the next stage's DMA instructions issued between them;
 //   * the 128 x 384 fp32 result leaves through the ring's LDS as two 64-row tiles, each normalised row-wise
 //     exactly as in layernorm2_kernel.
 // Replaces gemm_f16_kernel<2> + layernorm2_kernel on the index-build side (65 536 tokens of MiniLM: out-proj
 // 64 us + 47 us, FFN-down 147 us + 47 us before).  Measured: the pair of fused launches costs ~245 us per layer
 // (was 305), i.e. ~4 us per 64 KB chunk and CU -- the same ~16-20 GB/s per CU an HBM sweep delivers, although W
-// comes from L2; neither deeper prefetch, nor 128-byte pieces (the default: KC = 64, two stages), nor rotating
-// the K walk per workgroup moved it by more than a few per cent.
+// comes from L2; neither deeper prefetch, nor 128-byte pieces, nor rotating the K walk per workgroup moved it by
+// more than a few per cent.
 constexpr int kStageInstrPerWave(int kc) { return (128 + 384) * (kc / 8) / 64 / 8; }   // 4 (KC 32) or 8 (KC 64)
 constexpr int kR2Rows = 128, kR2H = 384;
 constexpr int kR2StageRows = kR2Rows + kR2H;                  // 512
-// (KC, stages) = (32, 4): 64-byte row pieces, three chunks in flight; (64, 2): 128-byte pieces, one in flight
 template <int KC, int NST>
 struct R2 {
   static constexpr int kCpr = KC / 8;                          // 16-byte pieces per row: 4 or 8
@@ -392,24 +208,6 @@ int gemm_rowln2_launch(const _Float16* a, const _Float16* w, const float* bias, 
   if (variant) hipLaunchKernelGGL(k1, dim3((m + kR2Rows - 1) / kR2Rows), dim3(kRlThreads), lds, stream, a, w, bias, residual, g, b, eps, m, k, x32, x16);
   else hipLaunchKernelGGL(k0, dim3((m + kR2Rows - 1) / kR2Rows), dim3(kRlThreads), lds, stream, a, w, bias, residual, g, b, eps, m, k, x32, x16);
   return (int)hipGetLastError();
-}
-
-namespace {
-}  // namespace
-
-// hidden sizes the fused kernel is instantiated for; K must be a multiple of its chunk (64 / 32)
-bool gemm_rowln_supported(int hidden, int k) {
-  if (hidden == 384) return k % 64 == 0;
-  if (hidden == 768) return k % 32 == 0;
-  return false;
-}
-
-int gemm_rowln_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, const float* g,
-                      const float* b, float eps, int m, int hidden, int k, float* x32, _Float16* x16,
-                      hipStream_t stream) {
-  if (!gemm_rowln_supported(hidden, k)) return -1;
-  if (hidden == 384) return launch_rowln<384>(a, w, bias, residual, g, b, eps, m, k, x32, x16, stream);
-  return launch_rowln<768>(a, w, bias, residual, g, b, eps, m, k, x32, x16, stream);
 }
 
 }  // namespace crs

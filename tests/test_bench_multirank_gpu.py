@@ -3,8 +3,8 @@ GPU per rank).  Everything else is the real path -- graph-captured device segmen
 shard (over-fetch k' = 16), the fp32 shadow re-rank written straight into the rank's wire block, ONE all-gather
 of the wire blocks and the final merge -- and bench.py itself checks the exchanged result against the exact
 fp64 ranking of the unquantised rows of both shards (config.recall_at_10_vs_fp32, config.check_ok; it exits
-non-zero when that check fails).  Strong scaling (the default: fixed corpus split over the ranks, replicated
-64-query batch, one collective per batch) and weak scaling (queries all-gathered first: the wide scan kernel)."""
+non-zero when that check fails).  Strong scaling (the default: fixed corpus split over the ranks, fixed 64-query batch
+encoded in shards and all-gathered, or replicated with one collective per batch) and weak scaling (queries all-gathered first: the wide scan kernel)."""
 import json
 import os
 import subprocess
@@ -29,15 +29,23 @@ def _run(extra, port):
 
 
 def test_two_rank_strong_step_is_exact_vs_fp32(cuda):
-    d = _run(["--workload", "c4", "--rows", "600000"], 29533)
+    d = _run(["--workload", "c4", "--rows", "600000", "--encode", "sharded"], 29533)    # (auto shards from 4 GPUs on)
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert c["corpus_rows"] == 600_000 and c["rows_per_gpu"] == 300_000 and c["queries_per_batch"] == 64
-    assert c["queries_per_step"] == 64 * 3 and c["collectives_per_batch"] == 1
+    assert c["queries_per_step"] == 64 * 3 and c["collectives_per_batch"] == 2
+    assert c["query_encode"].startswith("sharded: 32 of 64")            # each rank encodes half of the global batch
     assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
     assert c["recall_at_10_vs_fp32"]["max_abs_score_err_vs_fp64"] < 1e-5
     assert c["hip_graph"] is True and c["refine_fp32"] is True
     assert "scan_tb_kernel" in d["roofline"]["kernel"]
+
+
+def test_two_rank_strong_step_replicated_encode_is_one_collective(cuda):
+    d = _run(["--workload", "c4", "--rows", "600000"], 29536)                           # N = 2 default: replicated
+    c = d["config"]
+    assert c["collectives_per_batch"] == 1 and c["query_encode"] == "replicated"
+    assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
 
 
 def test_two_rank_weak_step_is_exact_vs_fp32(cuda):
