@@ -348,6 +348,7 @@ template <int MODE>
 int launch_panel(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
                  int splitk, int kin, hipStream_t stream) {
   const long wgs64 = (long)((n + PN - 1) / PN) * ((m + 63) / 64) * splitk;
+  // (forcing 64- or 128-row tiles everywhere measured within 2 % either way on both models' query chains)
   if (wgs64 > 256 && m > 64) return launch_panel_t<MODE, 128>(a, w, bias, out, m, n, k, kc, splitk, kin, stream);
   return launch_panel_t<MODE, 64>(a, w, bias, out, m, n, k, kc, splitk, kin, stream);
 }

@@ -196,6 +196,10 @@ class EmbeddingModel:
         if n == 0:
             return out
         token_ids = self.tokenize(texts)
+        if n <= self.batch_size:   # one batch: no length sort, no scatter (its index tensor is a blocking H2D copy per call)
+            ids, lens = pad_batch(token_ids, getattr(self.tokenizer, "pad_id", 0),
+                                  short_steps=tuple(st for st in (16, 32, 64) if st <= self.shape.max_seq))
+            return self.model.forward(ids, lens, normalize=bool(self.normalize), out=out)
         # longest first, like SentenceTransformer.encode: least padding per batch
         order = sorted(range(n), key=lambda i: -len(texts[i]))
         for lo in range(0, n, self.batch_size):

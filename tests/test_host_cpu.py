@@ -366,3 +366,20 @@ def test_document_processor_matches_reference_goldens(tmp_path):
     (tmp_path / "x.docx").write_text("x")
     with pytest.raises(ValueError):
         dp.process_file(str(tmp_path / "x.docx"))
+
+
+def test_ascii_fast_path_of_basic_tokenize_equals_the_general_path():
+    import random
+    from rag import tokenizer as tk
+    rnd = random.Random(3)
+    alphabet = [chr(c) for c in range(0, 128)]
+    for _ in range(300):
+        text = "".join(rnd.choice(alphabet) if rnd.random() < 0.3 else rnd.choice("abcXYZ 019.,-'\t\n") for _ in range(rnd.randint(0, 80)))
+        for lower in (True, False):
+            fast = tk.basic_tokenize(text, lower)
+            slow = tk.basic_tokenize(text + "\u00e9", lower)       # a non-ASCII tail forces the general path
+            assert slow[:len(fast)] == fast or slow[:-1] == fast[:-1], (repr(text), fast, slow)
+            # exact check: general path on the same text with the tail token removed
+            tail = tk.basic_tokenize("x \u00e9", lower)[-1]
+            gen = tk.basic_tokenize(text + " " + "\u00e9", lower)
+            assert gen[-1] == tail and gen[:-1] == fast, (repr(text), fast, gen)
