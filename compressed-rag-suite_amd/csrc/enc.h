@@ -22,7 +22,7 @@ int gemm_stream_launch(const _Float16* a, const _Float16* w, const float* bias, 
 // Panel variant for small M (one K chunk per workgroup, all loads issued at once; split-K over
 // blockIdx.z with fp32 partials [k/kc][M][N] in mode 3, summed by layernorm_launch).
 int gemm_panel_chunk(int k);
-int gemm_panel_splits(int k);   // fp32 partial slabs a mode-3 panel launch leaves for contraction length k
+int gemm_panel_splits(int k, int m);   // fp32 partial slabs a mode-3 panel launch of m rows leaves for contraction length k
 int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
                       int mode, hipStream_t stream);
 

@@ -46,15 +46,18 @@ struct Layout {
 // Small token counts are latency-bound: use the one-shot panel GEMM (+ split-K partials reduced in
 // the LayerNorm); large ones (index build) use the pipelined 128 x 128 kernel.
 constexpr int kPanelMaxTokens = 4096;
-// split-K panels (fp32 partials summed by the LayerNorm) pay off only while the launch is latency-bound: measured at
-// 1024 tokens they beat the tiled kernel (MiniLM step 0.140 vs 0.156 ms; bge equal), at 4096 tokens of bge they lose
-// badly (C3 step 2.79 ms with 2- and 8-way splits against 2.05 ms through the tiled kernel's fused epilogue)
-constexpr int kSplitKMaxTokens = 2048;
+// split-K panels (fp32 partials summed by the LayerNorm): round 1 measured them losing at 4096 tokens of bge (C3 step 2.79 ms
+// against 2.05 through the tiled kernel's fused epilogue) -- with one-shot 384-column staging and 2 / 8 slabs.  With the
+// workgroups walking their K range in 128-column pieces and the slab count capped by the row count (gemm_panel_splits) they
+// win there too: bge-base 256 x 16 tokens 1996 -> 1855 us per forward, 128 x 16: 1232 -> 1132
+constexpr int kSplitKMaxTokens = 4096;
 bool use_panel(int tokens, int k) {
   const int kc = crs::gemm_panel_chunk(k);
   if (tokens > kPanelMaxTokens || kc == 0) return false;
-  if (k / kc > 1 && tokens > kSplitKMaxTokens) return false;
-  const int ns = k / kc;   // split counts the LayerNorm kernel is instantiated for
+  static int splitk_max_tokens = -1;   // CRS_SPLITK_MAX_TOKENS: A/B runs
+  if (splitk_max_tokens < 0) { const char* e = getenv("CRS_SPLITK_MAX_TOKENS"); splitk_max_tokens = e ? atoi(e) : kSplitKMaxTokens; }
+  if (k / kc > 1 && tokens > splitk_max_tokens) return false;
+  const int ns = crs::gemm_panel_splits(k, tokens);   // slab counts the LayerNorm kernel is instantiated for
   return ns == 1 || ns == 2 || ns == 3 || ns == 4 || ns == 6 || ns == 8;
 }
 
@@ -63,8 +66,8 @@ Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
   Layout l;
   size_t off = 0;
   int split = 1;
-  if (use_panel((int)t, (int)f)) split = crs::gemm_panel_splits((int)f);
-  if (use_panel((int)t, (int)h) && crs::gemm_panel_splits((int)h) > split) split = crs::gemm_panel_splits((int)h);
+  if (use_panel((int)t, (int)f)) split = crs::gemm_panel_splits((int)f, (int)t);
+  if (use_panel((int)t, (int)h) && crs::gemm_panel_splits((int)h, (int)t) > split) split = crs::gemm_panel_splits((int)h, (int)t);
   l.max_split = split;
   l.x32 = off; off += up256(t * h * 4);
   l.y32 = off; off += up256(t * h * 4 * split);
@@ -164,7 +167,7 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
       CRS_TRY(crs::gemm_rowln2_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out projection + layernorm 1");
     } else if (panel_h) {
       CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, st), "out gemm");
-      CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(H), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
+      CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(H, T), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
@@ -175,7 +178,7 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
       CRS_TRY(crs::gemm_rowln2_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down projection + layernorm 2");
     } else if (panel_f) {
       CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, st), "ffn down gemm");
-      CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(F), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+      CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(F, T), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, y32, T, H, F, 2, st), "ffn down gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");

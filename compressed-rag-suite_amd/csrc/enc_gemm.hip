@@ -389,22 +389,24 @@ int gemm_panel_chunk(int k) {
   return 0;
 }
 
-// How many fp32 partial slabs a mode-3 launch over contraction length k leaves (the LayerNorm kernel that follows sums
-// them): k / chunk, capped at kPanelMaxSplit -- past that the workgroups walk several chunks each (kernel: kin).  8- and
-// 4-way splits of bge-base's FFN-down (K = 3072) measured the same at 64 queries; 2-way was slower (fewer workgroups).
-constexpr int kPanelMaxSplit = 8;
-int gemm_panel_splits(int k) {
+// How many fp32 partial slabs a mode-3 launch of m rows over contraction length k leaves (the LayerNorm kernel that
+// follows sums them): k / chunk, capped -- past the cap the workgroups walk several chunks each (kernel: kin).  The
+// cap falls with the row count, because the slabs are m x N x 4 bytes each and the launch no longer lacks workgroups
+// (bge-base FFN-down, K = 3072, tools/enc_chain_profile.py, whole forward): 1024 tokens: 8 / 4 / 2 slabs = 806 / 792 /
+// 850 us; 2048 tokens: - / 1138 / 1132; 4096 tokens: 2109 / 1945 / 1855 (and 1996 through the 128 x 128 kernel).
+int gemm_panel_splits(int k, int m) {
   const int kc = gemm_panel_chunk(k);
   if (kc == 0) return 0;
-  static int cap = -1;   // CRS_PANEL_MAX_SPLIT: A/B runs
-  if (cap < 0) { const char* e = getenv("CRS_PANEL_MAX_SPLIT"); cap = e ? atoi(e) : kPanelMaxSplit; if (cap < 1) cap = kPanelMaxSplit; }
+  static int cap_env = -1;   // CRS_PANEL_MAX_SPLIT: A/B runs
+  if (cap_env < 0) { const char* e = getenv("CRS_PANEL_MAX_SPLIT"); cap_env = e ? atoi(e) : 0; }
+  const int cap = cap_env > 0 ? cap_env : (m <= 1024 ? 4 : 2);
   int s = k / kc;
   while (s > cap && (s % 2) == 0) s /= 2;
   return s;
 }
 
 // out: mode 0/1 fp16 [M,N] (any k that is a multiple of the chunk: the workgroup walks the chunks); mode 3 fp32
-// [gemm_panel_splits(k)][M][N] partials
+// [gemm_panel_splits(k, m)][M][N] partials
 int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
                       int mode, hipStream_t stream) {
   const int kc = gemm_panel_chunk(k);
@@ -414,7 +416,7 @@ int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, v
     case 0: return launch_panel<0>(a, w, bias, out, m, n, k, kc, 1, chunks, stream);
     case 1: return launch_panel<1>(a, w, bias, out, m, n, k, kc, 1, chunks, stream);
     case 3: {
-      const int splitk = gemm_panel_splits(k);
+      const int splitk = gemm_panel_splits(k, m);
       return launch_panel<3>(a, w, bias, out, m, n, k, kc, splitk, chunks / splitk, stream);
     }
     default: return -1;

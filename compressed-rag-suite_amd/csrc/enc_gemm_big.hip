@@ -11,11 +11,14 @@
 // eight transfer instructions per wave and k-step (760 cycles of issue) outweigh the sixteen MFMAs they feed (512
 // cycles): 380-400 TFLOP/s on bge-base's shapes.  Here a workgroup owns 256 x BN (BN = 256: 128 flop per staged byte;
 // BN = 128: 85), eight waves as 4 (rows) x 2 (columns), a wave tile of 64 x BN/2 = 2 x (BN/64) MFMA tiles
-// (v_mfma_f32_32x32x16_f16; 128 or 64 accumulator registers), BK = 64 per stage, two stages of LDS fed by LDS-DMA
-// (source-side swizzle), one barrier per k-step; per k-step and wave 8 (or 6) transfer instructions against 32 (16)
-// MFMAs.  One workgroup per CU (128 / 96 KB of LDS), two waves per SIMD: one multiplies while the other issues.
+// (v_mfma_f32_32x32x16_f16; 128 accumulator registers), 32 columns of K per stage, FOUR stages of LDS fed by LDS-DMA
+// (source-side swizzle) with three in flight behind counted vmcnt waits, one barrier per k-step; per k-step and wave 4
+// transfer instructions against 16 MFMAs.  (A first cut with two 64-deep stages and a vmcnt(0) per k-step had one stage
+// in flight: a k-step's 1 us of MFMAs cannot cover a 1.5-2 us fetch.)  One workgroup per CU (128 KB of LDS), two waves
+// per SIMD: one multiplies while the other issues.
 // The epilogue leaves through wave-private LDS tiles as 16-byte row-contiguous stores (enc_gemm.hip's panel kernel).
 #include "enc.h"
+#include "lds_dma.h"
 
 #include <stdlib.h>
 
@@ -28,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int GM = 256, GK = 64;
+constexpr int GM = 256, GK = 32, GS = 4;   // rows per workgroup; contraction depth per stage; LDS stages (three in flight)
 constexpr int kBigThreads = 512;
 
 __device__ __forceinline__ float gelu_erf_b(float x) {   // Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), as enc_gemm.hip
@@ -39,18 +42,23 @@ __device__ __forceinline__ float gelu_erf_b(float x) {   // Abramowitz & Stegun 
   return 0.5f * x * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
 }
 
-__device__ __forceinline__ int lds_off_b(int row, int chunk) {  // 128-byte rows, 8 x 16-byte chunks, swizzled by row
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
+// 64-byte LDS rows (GK = 32 halves), 4 x 16-byte chunks: rows 4 apart share banks, so the chunk index is XORed with
+// (row >> 2) & 3 -- the 16 rows a 16-lane read group touches then cover all 64 banks
+__device__ __forceinline__ int lds_off_b(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int MODE, int BN>
 __global__ __launch_bounds__(kBigThreads, 2) void gemm_big_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                                  const float* __restrict__ bias, const float* __restrict__ residual,
                                                                  void* __restrict__ out, int M, int N, int K) {
   constexpr int NT = BN / 64;                       // 32-column MFMA tiles per wave (wave tile 64 x BN/2)
-  constexpr int kStage = (GM + BN) * GK * 2;        // bytes per stage: 64 KB (BN 256) / 48 KB (BN 128)
-  constexpr int kLa = GM * 8 / kBigThreads;         // 16-byte chunks of the A panel per thread: 4
-  constexpr int kLw = BN * 8 / kBigThreads;         // ... of the W panel: 4 / 2
+  constexpr int kStage = (GM + BN) * GK * 2;        // bytes per stage: 32 KB (BN 256)
+  constexpr int kLa = GM * 4 / kBigThreads;         // 16-byte chunks of the A panel per thread and stage: 2
+  constexpr int kLw = BN * 4 / kBigThreads;         // ... of the W panel: 2
+  constexpr int kL = kLa + kLw;                     // transfer instructions per wave and stage: 4
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,25 +67,27 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_big_kernel(const _Float16
   const int ncb = (N + BN - 1) / BN;
   const int m0 = ((int)blockIdx.x / ncb) * GM, n0 = ((int)blockIdx.x % ncb) * BN;
 
-  const _Float16* ga[kLa];
-  const _Float16* gw[kLw];
+  // LDS position P = j * 512 + tid (16-byte units) of a panel = (row P >> 2, slot P & 3) receives source chunk
+  // slot ^ ((row >> 2) & 3) of that row (source-side swizzle; the transfer writes LDS linearly)
+  const char* ga[kLa];
+  const char* gw[kLw];
 #pragma unroll
   for (int j = 0; j < kLa; ++j) {
-    const int id = j * kBigThreads + tid, row = id >> 3, cp = id & 7;
-    ga[j] = A + (size_t)min(m0 + row, M - 1) * K + ((cp ^ ((row >> 1) & 7)) << 3);
+    const int id = j * kBigThreads + tid, row = id >> 2, cp = id & 3;
+    ga[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + row, M - 1) * K) + ((cp ^ ((row >> 2) & 3)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < kLw; ++j) {
-    const int id = j * kBigThreads + tid, row = id >> 3, cp = id & 7;
-    gw[j] = W + (size_t)min(n0 + row, N - 1) * K + ((cp ^ ((row >> 1) & 7)) << 3);
+    const int id = j * kBigThreads + tid, row = id >> 2, cp = id & 3;
+    gw[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + row, N - 1) * K) + ((cp ^ ((row >> 2) & 3)) << 4);
   }
-  auto stage = [&](int buf, int k0) {
-    char* sa = bsm + buf * kStage + wave * 1024;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)bsm + (unsigned)wave * 1024u);
+  auto stage = [&](int buf, int k0) {   // k0 in halves; asm transfers (lds_dma.h): counted by hand, not by the compiler
+    const unsigned d0 = lds_wave + (unsigned)(buf * kStage);
 #pragma unroll
-    for (int j = 0; j < kLa; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ga[j] + k0), (lptr_t)(sa + j * (kBigThreads * 16)), 16, 0, 0);
+    for (int j = 0; j < kLa; ++j) lds_dma16(d0 + (unsigned)(j * kBigThreads * 16), ga[j] + (size_t)k0 * 2);
 #pragma unroll
-    for (int j = 0; j < kLw; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(gw[j] + k0), (lptr_t)(sa + GM * 128 + j * (kBigThreads * 16)), 16, 0, 0);
+    for (int j = 0; j < kLw; ++j) lds_dma16(d0 + (unsigned)(GM * 64 + j * kBigThreads * 16), gw[j] + (size_t)k0 * 2);
   };
 
   f32x16 acc[2][NT];
@@ -89,34 +99,36 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_big_kernel(const _Float16
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = 0; k0 < K; k0 += GK) {
-    if (k0 + GK < K) stage(cur ^ 1, k0 + GK);     // next stage in flight under this stage's MFMAs
-    const char* sa = bsm + cur * kStage;
-    const char* sw = sa + GM * 128;
+  const int nk = K / GK;                            // k-steps (K is a multiple of 64)
+  // prologue: stages 0 .. GS - 2 in flight
+#pragma unroll
+  for (int s = 0; s < GS - 1; ++s)
+    if (s < nk) stage(s, s * GK);
+  for (int i = 0; i < nk; ++i) {
+    // stage i must have landed; the (up to) two younger stages may stay in flight
+    const int younger = min(nk - 1 - i, GS - 2);
+    if (younger >= 2) wait_vm<2 * kL>(); else if (younger == 1) wait_vm<kL>(); else wait_vm<0>();
+    __syncthreads();                                 // every wave's share of stage i is in LDS; stage i - 1's buffer is free
+    if (i + GS - 1 < nk) stage((i + GS - 1) % GS, (i + GS - 1) * GK);
+    const char* sa = bsm + (i % GS) * kStage;
+    const char* sw = sa + GM * 64;
 #pragma unroll
     for (int ks = 0; ks < GK / 16; ++ks) {
       f16x8 af[2], bf[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(sa + lds_off_b(wm * 64 + i * 32 + fr, ks * 2 + fh));
+      for (int ii = 0; ii < 2; ++ii) af[ii] = *reinterpret_cast<const f16x8*>(sa + lds_off_b(wm * 64 + ii * 32 + fr, ks * 2 + fh));
 #pragma unroll
       for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sw + lds_off_b(wn * (BN / 2) + j * 32 + fr, ks * 2 + fh));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ii], bf[j], acc[ii][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
   }
+  __syncthreads();   // all fragment reads done: the stage buffers become the waves' output tiles
 
-  // ---- epilogue: one 32 x 32 accumulator tile at a time through this wave's private LDS tile (the stage buffers are
-  // free after the last barrier), then 16-byte row-contiguous loads / stores.  Lane holds column (lane & 31), rows
-  // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of a tile.
+  // ---- epilogue: one 32 x 32 accumulator tile at a time through this wave's private LDS tile, then 16-byte
+  // row-contiguous loads / stores.  Lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of a tile.
   constexpr int TS = 36;                            // floats per tile row (144 bytes: 16-byte aligned, bank-spread)
   float* my = reinterpret_cast<float*>(bsm) + wave * (32 * TS);
 #pragma unroll
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_big_kernel(const _Float16
 template <int MODE, int BN>
 int launch_big(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k,
                hipStream_t stream) {
-  constexpr int lds = 2 * (GM + BN) * GK * 2;
+  constexpr int lds = GS * (GM + BN) * GK * 2;
   static bool done = false;
   auto kernel = &gemm_big_kernel<MODE, BN>;
   if (!done) {
