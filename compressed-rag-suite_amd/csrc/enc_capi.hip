@@ -48,9 +48,12 @@ struct Layout {
 constexpr int kPanelMaxTokens = 4096;
 // split-K panels (fp32 partials summed by the LayerNorm): round 1 measured them losing at 4096 tokens of bge (C3 step 2.79 ms
 // against 2.05 through the tiled kernel's fused epilogue) -- with one-shot 384-column staging and 2 / 8 slabs.  With the
-// workgroups walking their K range in 128-column pieces and the slab count capped by the row count (gemm_panel_splits) they
-// win there too: bge-base 256 x 16 tokens 1996 -> 1855 us per forward, 128 x 16: 1232 -> 1132
-constexpr int kSplitKMaxTokens = 4096;
+// workgroups walking their K range in 128-column pieces and the slab count capped by the row count (gemm_panel_splits) a
+// SINGLE forward at 4096 tokens is faster through split-K panels (bge-base 256 x 16 tokens: 1996 -> 1855 us, one stream), but
+// with eight batches in flight the extra slab traffic costs more than the latency it saves (C3: 2.21 against 2.11 ms per
+// batch, tools/ab_c3.sh) -- so the limit stays at 2048 tokens (bge-base 128 x 16: 1500 -> 1140 us); CRS_SPLITK_MAX_TOKENS
+// moves it
+constexpr int kSplitKMaxTokens = 2048;
 bool use_panel(int tokens, int k) {
   const int kc = crs::gemm_panel_chunk(k);
   if (tokens > kPanelMaxTokens || kc == 0) return false;
