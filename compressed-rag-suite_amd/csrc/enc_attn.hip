@@ -15,6 +15,8 @@
 
 #include "enc.h"
 
+#include <stdlib.h>
+
 namespace crs {
 namespace {
 
@@ -157,11 +159,139 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-sequence variant for sequences of at most 256 tokens (MiniLM's max_seq_length; index build): one workgroup per
+// (batch, head) stages K and V^T of the WHOLE sequence once (HD = 32: 18 + 17 KB of LDS, one barrier) and its four
+// waves walk the query tiles (16 queries each: tiles w, w + 4, ...) over all key blocks without further barriers.
+// The kernel above gives each 64-query block its own workgroup, which re-stages the same K / V per query block and
+// pays two barriers and an unprefetched global round trip per 64 keys -- at 256-token sequences four times the loads
+// and eight barriers for 16 small MFMAs per block.  Arithmetic, masking and output are identical (same accumulation
+// order per query), so the results are bit-equal to the blocked kernel's.
+template <int HD, int SMAX>
+__global__ __launch_bounds__(kThreads) void attention_seq_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ lens,
+                                                                _Float16* __restrict__ ctx, int seq, int hidden) {
+  constexpr int KS = HD / 16, NT = HD / 16;
+  constexpr int KROW = HD + 4, VROW = SMAX + 4;
+  __shared__ __attribute__((aligned(16))) _Float16 sK[SMAX * KROW];
+  __shared__ __attribute__((aligned(16))) _Float16 sVt[HD * VROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int len = min(max(lens[b], 1), seq);
+  const size_t row_stride = (size_t)3 * hidden;
+  const _Float16* base = qkv + (size_t)b * seq * row_stride + h * HD;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int kend = (len + KB - 1) / KB * KB;       // keys staged: whole 64-key blocks up to len (rows >= seq are zero)
+
+  constexpr int CH = HD / 8;
+  for (int id = tid; id < kend * CH; id += kThreads) {
+    const int key = id / CH, c = id % CH;
+    f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (key < seq) kv = *reinterpret_cast<const f16x8*>(base + (size_t)key * row_stride + c * 8 + hidden);
+    *reinterpret_cast<f16x4*>(&sK[key * KROW + c * 8]) = f16x4{kv[0], kv[1], kv[2], kv[3]};
+    *reinterpret_cast<f16x4*>(&sK[key * KROW + c * 8 + 4]) = f16x4{kv[4], kv[5], kv[6], kv[7]};
+  }
+  for (int id = tid; id < (kend / 4) * CH; id += kThreads) {
+    const int kg = id / CH, c = id % CH;
+    f16x8 vv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kr = kg * 4 + j;
+      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      vv[j] = (kr < seq) ? *reinterpret_cast<const f16x8*>(base + (size_t)kr * row_stride + c * 8 + 2 * hidden) : z;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      *reinterpret_cast<f16x4*>(&sVt[(c * 8 + e) * VROW + kg * 4]) = f16x4{vv[0][e], vv[1][e], vv[2][e], vv[3][e]};
+  }
+  __syncthreads();
+
+  for (int q0 = wave * 16; q0 < seq; q0 += 4 * 16) {
+    f16x4 qf[KS];
+    const int qr = q0 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f16x4 z = {0, 0, 0, 0};
+      qf[ks] = (qr < seq) ? *reinterpret_cast<const f16x4*>(base + (size_t)qr * row_stride + ks * 16 + g * 4) : z;
+    }
+    f32x4 o[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+    for (int kb = 0; kb < len; kb += KB) {
+      f32x4 sc[4];
+      float mx = -1e30f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        sc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const f16x4 kf = *reinterpret_cast<const f16x4*>(&sK[(kb + ct * 16 + lr) * KROW + ks * 16 + g * 4]);
+          sc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[ks], sc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool valid = (kb + ct * 16 + 4 * g + i) < len;
+          sc[ct][i] = valid ? sc[ct][i] * scale : -1e30f;
+          mx = fmaxf(mx, sc[ct][i]);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mn = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - mn);
+      m_run = mn;
+      float rs = 0.f;
+      f16x4 pf[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = __expf(sc[ct][i] - mn);
+          rs += p;
+          pf[ct][i] = (_Float16)p;
+        }
+      }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      l_run = l_run * alpha + rs;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[n][i] *= alpha;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const f16x4 vf = *reinterpret_cast<const f16x4*>(&sVt[(n * 16 + lr) * VROW + kb + ct * 16 + g * 4]);
+          o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf[ct], o[n], 0, 0, 0);
+        }
+      }
+    }
+    if (qr < seq) {
+      const float inv = 1.0f / l_run;
+      _Float16* dst = ctx + ((size_t)b * seq + qr) * hidden + h * HD;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const f16x4 v = {(_Float16)(o[n][0] * inv), (_Float16)(o[n][1] * inv), (_Float16)(o[n][2] * inv), (_Float16)(o[n][3] * inv)};
+        *reinterpret_cast<f16x4*>(dst + n * 16 + 4 * g) = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,
                      int heads, hipStream_t stream) {
   const int hd = hidden / heads;
+  // whole sequence per workgroup when it is long enough to matter and short enough for LDS (CRS_ATTN_SEQ=0: off)
+  static int seq_on = -1;
+  if (seq_on < 0) { const char* e = getenv("CRS_ATTN_SEQ"); seq_on = (e && e[0] == '0') ? 0 : 1; }
+  if (seq_on && seq > 64 && seq <= 256 && (hd == 32 || hd == 16)) {
+    dim3 g2(heads, batch);
+    if (hd == 32) hipLaunchKernelGGL((attention_seq_kernel<32, 256>), g2, dim3(kThreads), 0, stream, qkv, lens, ctx, seq, hidden);
+    else hipLaunchKernelGGL((attention_seq_kernel<16, 256>), g2, dim3(kThreads), 0, stream, qkv, lens, ctx, seq, hidden);
+    return (int)hipGetLastError();
+  }
   dim3 grid((seq + QB - 1) / QB, heads, batch);
   switch (hd) {
     case 16: hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(kThreads), 0, stream, qkv, lens, ctx, seq, hidden); break;
