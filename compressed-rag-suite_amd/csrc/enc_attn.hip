@@ -160,20 +160,23 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Whole-sequence variant for sequences of at most 256 tokens (MiniLM's max_seq_length; index build): one workgroup per
-// (batch, head) stages K and V^T of the WHOLE sequence once (HD = 32: 18 + 17 KB of LDS, one barrier) and its four
-// waves walk the query tiles (16 queries each: tiles w, w + 4, ...) over all key blocks without further barriers.
+// Whole-sequence variant (index build): one workgroup per (batch, head) stages K and V^T of the WHOLE sequence once
+// (head_dim 32, <= 256 tokens: 18 + 17 KB of LDS, four waves; head_dim 64, <= 512 tokens: 70 + 66 KB, eight waves; one
+// barrier) and its waves walk the query tiles (16 queries each: tiles w, w + NW, ...) over all key blocks without
+// further barriers.
 // The kernel above gives each 64-query block its own workgroup, which re-stages the same K / V per query block and
 // pays two barriers and an unprefetched global round trip per 64 keys -- at 256-token sequences four times the loads
 // and eight barriers for 16 small MFMAs per block.  Arithmetic, masking and output are identical (same accumulation
 // order per query), so the results are bit-equal to the blocked kernel's.
-template <int HD, int SMAX>
-__global__ __launch_bounds__(kThreads) void attention_seq_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ lens,
-                                                                _Float16* __restrict__ ctx, int seq, int hidden) {
+template <int HD, int SMAX, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_seq_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ lens,
+                                                               _Float16* __restrict__ ctx, int seq, int hidden) {
   constexpr int KS = HD / 16, NT = HD / 16;
   constexpr int KROW = HD + 4, VROW = SMAX + 4;
-  __shared__ __attribute__((aligned(16))) _Float16 sK[SMAX * KROW];
-  __shared__ __attribute__((aligned(16))) _Float16 sVt[HD * VROW];
+  constexpr int kThreads = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) char attn_smem[];
+  _Float16* sK = reinterpret_cast<_Float16*>(attn_smem);                       // [SMAX][KROW]
+  _Float16* sVt = sK + SMAX * KROW;                                            // [HD][VROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int b = blockIdx.y, h = blockIdx.x;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void attention_seq_kernel(const _Float16*
   }
   __syncthreads();
 
-  for (int q0 = wave * 16; q0 < seq; q0 += 4 * 16) {
+  for (int q0 = wave * 16; q0 < seq; q0 += NW * 16) {
     f16x4 qf[KS];
     const int qr = q0 + lr;
 #pragma unroll
@@ -286,11 +289,18 @@ int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int ba
   // whole sequence per workgroup when it is long enough to matter and short enough for LDS (CRS_ATTN_SEQ=0: off)
   static int seq_on = -1;
   if (seq_on < 0) { const char* e = getenv("CRS_ATTN_SEQ"); seq_on = (e && e[0] == '0') ? 0 : 1; }
-  if (seq_on && seq > 64 && seq <= 256 && (hd == 32 || hd == 16)) {
+  if (seq_on && seq > 64) {
     dim3 g2(heads, batch);
-    if (hd == 32) hipLaunchKernelGGL((attention_seq_kernel<32, 256>), g2, dim3(kThreads), 0, stream, qkv, lens, ctx, seq, hidden);
-    else hipLaunchKernelGGL((attention_seq_kernel<16, 256>), g2, dim3(kThreads), 0, stream, qkv, lens, ctx, seq, hidden);
-    return (int)hipGetLastError();
+    auto launch = [&](auto kernel, int threads, int lds) -> int {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(kernel, g2, dim3(threads), lds, stream, qkv, lens, ctx, seq, hidden);
+      return (int)hipGetLastError();
+    };
+    if (hd == 32 && seq <= 256) return launch(&attention_seq_kernel<32, 256, 4>, 256, (256 * 36 + 32 * 260) * 2);
+    if (hd == 16 && seq <= 256) return launch(&attention_seq_kernel<16, 256, 4>, 256, (256 * 20 + 16 * 260) * 2);
+    if (hd == 64 && seq <= 512 && seq > 256) return launch(&attention_seq_kernel<64, 512, 8>, 512, (512 * 68 + 64 * 516) * 2);
+    if (hd == 64 && seq <= 256) return launch(&attention_seq_kernel<64, 256, 4>, 256, (256 * 68 + 64 * 260) * 2);
   }
   dim3 grid((seq + QB - 1) / QB, heads, batch);
   switch (hd) {
