@@ -5,6 +5,14 @@
 
 namespace crs {
 
+// Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own L2.  xcd_chunked_id turns the hardware id into
+// a work index such that every XCD walks ONE contiguous range of indices (in id order): tiles that share an operand
+// panel are neighbours in index space, so they meet in the same L2 instead of being fetched by eight of them.
+__device__ __forceinline__ int xcd_chunked_id(int id, int total) {
+  const int x = id & 7, q = total >> 3, r = total & 7;
+  return x * q + (x < r ? x : r) + (id >> 3);
+}
+
 // enc_gemm.hip: C = epilogue(A[M,K] W[N,K]^T + bias); mode 0 fp16, 1 GELU fp16, 2 +residual fp32
 int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual,
                     void* out, int m, int n, int k, int mode, hipStream_t stream);

@@ -28,6 +28,45 @@ constexpr int kThreads = 256;
 constexpr int KB = 64;   // keys per block
 constexpr int QB = 64;   // query rows per workgroup
 
+// One online-softmax step for this lane's query over the 16 scores it holds of a 64-key block (raw Q.K products in s).
+// Works in the base-2 domain with the 1/sqrt(hd) scale folded into one constant c = log2(e) / sqrt(hd): per score a
+// max on the raw product, one fma and one v_exp_f32 (the softmax, not the MFMAs, bounds this kernel: 16 scores per
+// lane and block against 16 small MFMAs per wave).  Keys >= len (right padding, last block only) are set to -1e30
+// before the max, so their weight is exp2(-huge) = 0; every query sees key 0, so the running max is finite.
+__device__ __forceinline__ void softmax_step(f32x4 (&s)[4], int key0, int len, float c, float& m_run, float& l_run,
+                                             float& alpha, f16x4 (&pf)[4]) {
+  float mx = -1e30f;
+  if (key0 - (key0 & 15) + KB > len) {     // block reaches past len (wave-uniform: key0 = kb + 4 g)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (key0 + ct * 16 + i >= len) s[ct][i] = -1e30f;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[ct][i]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float mn = fmaxf(m_run, mx * c);
+  alpha = __builtin_amdgcn_exp2f(m_run - mn);
+  m_run = mn;
+  float rs = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[ct][i], c, -mn));
+      rs += p;
+      pf[ct][i] = (_Float16)p;
+    }
+  }
+  rs += __shfl_xor(rs, 16);
+  rs += __shfl_xor(rs, 32);
+  l_run = l_run * alpha + rs;
+}
+
 template <int HD>
 __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __restrict__ qkv,
                                                             const int* __restrict__ lens,
@@ -46,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __r
   const int len = min(max(lens[b], 1), seq);
   const size_t row_stride = (size_t)3 * hidden;
   const _Float16* base = qkv + (size_t)b * seq * row_stride + h * HD;
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = 1.44269504088896341f / sqrtf((float)HD);   // log2(e) / sqrt(hd): softmax_step works in base 2
 
   // Everything is computed TRANSPOSED: S^T = K Q^T and O^T = V^T P^T.  With the 16x16x16 accumulator layout
   // (column = lane & 15, rows 4 (lane >> 4) + i) a lane then holds the scores of ONE query (lane & 15) for 16
@@ -99,7 +138,6 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __r
 
     // ---- S^T = K Q^T for 4 tiles of 16 keys: lane holds keys kb + 16 ct + 4 g + i of query lr
     f32x4 s[4];
-    float mx = -1e30f;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       s[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -108,32 +146,10 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const _Float16* __r
         const f16x4 kf = *reinterpret_cast<const f16x4*>(&sK[(ct * 16 + lr) * KROW + ks * 16 + g * 4]);
         s[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[ks], s[ct], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool valid = (kb + ct * 16 + 4 * g + i) < len;
-        s[ct][i] = valid ? s[ct][i] * scale : -1e30f;
-        mx = fmaxf(mx, s[ct][i]);
-      }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mn = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - mn);
-    m_run = mn;
-    float rs = 0.f;
+    float alpha;
     f16x4 pf[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float p = __expf(s[ct][i] - mn);   // masked keys: exp(-1e30 - m) = 0
-        rs += p;
-        pf[ct][i] = (_Float16)p;
-      }
-    }
-    rs += __shfl_xor(rs, 16);
-    rs += __shfl_xor(rs, 32);
-    l_run = l_run * alpha + rs;
+    softmax_step(s, kb + 4 * g, len, scale, m_run, l_run, alpha, pf);
     // ---- O^T = O^T alpha + V^T P^T   (A = V^T[hd 16 n + lr][key 16 ct + 4 g + j], B = P^T from the registers)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -179,11 +195,17 @@ __global__ __launch_bounds__(NW * 64) void attention_seq_kernel(const _Float16* 
   _Float16* sVt = sK + SMAX * KROW;                                            // [HD][VROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y, h = blockIdx.x;
+  // (batch, head) unit of this workgroup.  Workgroups go round-robin over the 8 XCDs (id % 8), and two heads that are
+  // neighbours in a token's Q / K / V row share 128-byte lines when head_dim is 32: units 2p and 2p + 1 are given to
+  // the SAME XCD back to back (ids 16 j + x and 16 j + 8 + x), so the second one's K / V come out of that XCD's L2.
+  const int heads = hidden / HD;
+  int unit = blockIdx.x;
+  if ((gridDim.x & 15) == 0) unit = (((unit >> 4) << 3) + (unit & 7)) * 2 + ((unit >> 3) & 1);
+  const int b = unit / heads, h = unit % heads;
   const int len = min(max(lens[b], 1), seq);
   const size_t row_stride = (size_t)3 * hidden;
   const _Float16* base = qkv + (size_t)b * seq * row_stride + h * HD;
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = 1.44269504088896341f / sqrtf((float)HD);   // log2(e) / sqrt(hd): softmax_step works in base 2
   const int kend = (len + KB - 1) / KB * KB;       // keys staged: whole 64-key blocks up to len (rows >= seq are zero)
 
   constexpr int CH = HD / 8;
@@ -223,7 +245,6 @@ __global__ __launch_bounds__(NW * 64) void attention_seq_kernel(const _Float16* 
     float m_run = -1e30f, l_run = 0.f;
     for (int kb = 0; kb < len; kb += KB) {
       f32x4 sc[4];
-      float mx = -1e30f;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         sc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -232,32 +253,10 @@ __global__ __launch_bounds__(NW * 64) void attention_seq_kernel(const _Float16* 
           const f16x4 kf = *reinterpret_cast<const f16x4*>(&sK[(kb + ct * 16 + lr) * KROW + ks * 16 + g * 4]);
           sc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[ks], sc[ct], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool valid = (kb + ct * 16 + 4 * g + i) < len;
-          sc[ct][i] = valid ? sc[ct][i] * scale : -1e30f;
-          mx = fmaxf(mx, sc[ct][i]);
-        }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mn = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - mn);
-      m_run = mn;
-      float rs = 0.f;
+      float alpha;
       f16x4 pf[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float p = __expf(sc[ct][i] - mn);
-          rs += p;
-          pf[ct][i] = (_Float16)p;
-        }
-      }
-      rs += __shfl_xor(rs, 16);
-      rs += __shfl_xor(rs, 32);
-      l_run = l_run * alpha + rs;
+      softmax_step(sc, kb + 4 * g, len, scale, m_run, l_run, alpha, pf);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -290,7 +289,7 @@ int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int ba
   static int seq_on = -1;
   if (seq_on < 0) { const char* e = getenv("CRS_ATTN_SEQ"); seq_on = (e && e[0] == '0') ? 0 : 1; }
   if (seq_on && seq > 64) {
-    dim3 g2(heads, batch);
+    dim3 g2(heads * batch);
     auto launch = [&](auto kernel, int threads, int lds) -> int {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return (int)e;

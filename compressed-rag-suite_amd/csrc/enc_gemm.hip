@@ -61,7 +61,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // 1-D grid; the column blocks of one row block are neighbours in one XCD's range (enc.h) and share the A panel there
+  const int ncb = (N + BN - 1) / BN;
+  const int wid = xcd_chunked_id((int)blockIdx.x, (int)gridDim.x);
+  const int m0 = (wid / ncb) * BM, n0 = (wid % ncb) * BN;
 
   // staging by LDS-DMA: chunk P = j*256 + tid of a [128 rows][8 chunks] panel lands at LDS offset P*16
   // (linear); the bank swizzle chunk ^= (row >> 1) & 7 is applied to the SOURCE column instead.
@@ -368,7 +371,7 @@ int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, con
   if (gemm_big_block_n(m, n, k, mode) != 0) return gemm_big_launch(a, w, bias, residual, out, m, n, k, mode, stream);
   if (m >= 512 && n >= 512 && mode != 2 && gemm_stream_supported(k) && stream_enabled())
     return gemm_stream_launch(a, w, bias, residual, out, m, n, k, mode, stream);
-  dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
+  dim3 grid(((n + BN - 1) / BN) * ((m + BM - 1) / BM));
   switch (mode) {
     case 0: hipLaunchKernelGGL((gemm_f16_kernel<0>), grid, dim3(kThreads), 0, stream, a, w, bias, residual, out, m, n, k); break;
     case 1: hipLaunchKernelGGL((gemm_f16_kernel<1>), grid, dim3(kThreads), 0, stream, a, w, bias, residual, out, m, n, k); break;

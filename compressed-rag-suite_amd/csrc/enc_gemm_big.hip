@@ -63,9 +63,10 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_big_kernel(const _Float16
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // column blocks of one row block on consecutive ids: they share the A panel through L2
+  // column blocks of one row block are neighbours in one XCD's range: they share the A panel through that L2
   const int ncb = (N + BN - 1) / BN;
-  const int m0 = ((int)blockIdx.x / ncb) * GM, n0 = ((int)blockIdx.x % ncb) * BN;
+  const int wid = xcd_chunked_id((int)blockIdx.x, (int)gridDim.x);
+  const int m0 = (wid / ncb) * GM, n0 = (wid % ncb) * BN;
 
   // LDS position P = j * 512 + tid (16-byte units) of a panel = (row P >> 2, slot P & 3) receives source chunk
   // slot ^ ((row >> 2) & 3) of that row (source-side swizzle; the transfer writes LDS linearly)
