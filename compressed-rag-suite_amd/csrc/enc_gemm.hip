@@ -17,6 +17,7 @@
 // MFMA-bound for index-build batches (thousands of tokens); launch-bound for a single short query.
 
 #include "enc.h"
+#include "enc_gelu.h"
 
 #include <stdlib.h>
 
@@ -31,18 +32,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kThreads = 256;
 constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
-
-// erf-form GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7, far below the fp16 rounding of the stored activation); libm's erff costs
-// ~50 VALU instructions per element, this one ~15 with a single v_exp.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // 1-ulp reciprocal: one v_rcp_f32
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  const float erf = x < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * x * (1.0f + erf);
-}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {  // 128-byte rows, 8 x 16-byte chunks
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -163,9 +152,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
       if (gr >= M || gc >= N) continue;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = tile[row * BN + c8 + e] + ((bias && gc + e < N) ? bias[gc + e] : 0.f);
-        v[e] = (MODE == 1) ? gelu_erf(x) : x;
+      for (int e = 0; e < 8; e += 2) {
+        gelu_f32x2 x = {tile[row * BN + c8 + e] + ((bias && gc + e < N) ? bias[gc + e] : 0.f),
+                        tile[row * BN + c8 + e + 1] + ((bias && gc + e + 1 < N) ? bias[gc + e + 1] : 0.f)};
+        if (MODE == 1) x = gelu_erf2(x);
+        v[e] = x[0];
+        v[e + 1] = x[1];
       }
       const size_t at = (size_t)gr * N + gc;
       if (gc + 7 < N) {
@@ -294,10 +286,11 @@ __global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Flo
     constexpr int TS = 40;   // halves per tile row (80 bytes)
     _Float16* my = reinterpret_cast<_Float16*>(psm) + wave * (32 * TS);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = acc[r] + b;
-      if (MODE == 1) v = gelu_erf(v);
-      my[((r & 3) + 8 * (r >> 2) + 4 * fh) * TS + fr] = (_Float16)v;
+    for (int r = 0; r < 16; r += 2) {
+      gelu_f32x2 v = {acc[r] + b, acc[r + 1] + b};
+      if (MODE == 1) v = gelu_erf2(v);
+      my[((r & 3) + 8 * (r >> 2) + 4 * fh) * TS + fr] = (_Float16)v[0];
+      my[(((r + 1) & 3) + 8 * (r >> 2) + 4 * fh) * TS + fr] = (_Float16)v[1];
     }
     __builtin_amdgcn_wave_barrier();
     _Float16* o = reinterpret_cast<_Float16*>(out);

@@ -18,6 +18,7 @@
 // per SIMD: one multiplies while the other issues.
 // The epilogue leaves through wave-private LDS tiles as 16-byte row-contiguous stores (enc_gemm.hip's panel kernel).
 #include "enc.h"
+#include "enc_gelu.h"
 #include "lds_dma.h"
 
 #include <stdlib.h>
@@ -33,14 +34,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int GM = 256, GK = 32, GS = 4;   // rows per workgroup; contraction depth per stage; LDS stages (three in flight)
 constexpr int kBigThreads = 512;
-
-__device__ __forceinline__ float gelu_erf_b(float x) {   // Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), as enc_gemm.hip
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
-}
 
 // 64-byte LDS rows (GK = 32 halves), 4 x 16-byte chunks: rows 4 apart share banks, so the chunk index is XORed with
 // (row >> 2) & 3 -- the 16 rows a 16-lane read group touches then cover all 64 banks
@@ -156,14 +149,19 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_big_kernel(const _Float16
               typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
               f16x4 h;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) h[e] = (_Float16)(MODE == 1 ? gelu_erf_b(v[e]) : v[e]);
+              for (int e = 0; e < 4; e += 2) {
+                gelu_f32x2 x = {v[e], v[e + 1]};
+                if (MODE == 1) x = gelu_erf2(x);
+                h[e] = (_Float16)x[0];
+                h[e + 1] = (_Float16)x[1];
+              }
               *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(out) + at) = h;
             }
           } else {
             for (int e = 0; e < 4 && col + e < N; ++e) {
               float x = v[e] + (bias ? bias[col + e] : 0.f);
               if (MODE == 2) reinterpret_cast<float*>(out)[at + e] = x + residual[at + e];
-              else reinterpret_cast<_Float16*>(out)[at + e] = (_Float16)(MODE == 1 ? gelu_erf_b(x) : x);
+              else reinterpret_cast<_Float16*>(out)[at + e] = (_Float16)(MODE == 1 ? gelu_erf(x) : x);
             }
           }
         }

@@ -22,6 +22,7 @@
 
 #include "enc.h"
 #include "lds_dma.h"
+#include "enc_gelu.h"
 
 namespace crs {
 namespace {
@@ -34,14 +35,6 @@ constexpr int kThreads = 256;
 constexpr int TR = 32;     // A rows per tile
 constexpr int WN = 128;    // output columns per workgroup (4 waves x 32)
 constexpr int kEpiStride = 40;   // halves per row of the wave-private epilogue tile (32 + 8: 80-byte rows, 16-byte aligned)
-
-__device__ __forceinline__ float gelu_erf_s(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
-}
 
 template <int K, int MODE>
 __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16* __restrict__ A,
@@ -153,10 +146,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_stream_kernel(const _Float16
       // took longer than the tile's 24 MFMAs)
       _Float16* my = reinterpret_cast<_Float16*>(smem + 2 * kTileBytes) + wave * (32 * kEpiStride);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[r] + bcol;
-        if (MODE == 1) v = gelu_erf_s(v);
-        my[((r & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v;
+      for (int r = 0; r < 16; r += 2) {
+        gelu_f32x2 v = {acc[r] + bcol, acc[r + 1] + bcol};
+        if (MODE == 1) v = gelu_erf2(v);
+        my[((r & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v[0];
+        my[(((r + 1) & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v[1];
       }
       __builtin_amdgcn_wave_barrier();
       const int c0 = cblk * WN + wave * 32;            // first column of this wave's block
@@ -284,10 +278,11 @@ __global__ __launch_bounds__(kKsThreads, 2) void gemm_stream_ks_kernel(const _Fl
     const float* xb = xbuf + ((pair * 2 + (ie & 1)) * 16) * 64 + lane;
     _Float16* my = epi + pair * (32 * kEpiStride);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = (own[r] + xb[r * 64]) + bcol;
-      if (MODE == 1) v = gelu_erf_s(v);
-      my[((r & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v;
+    for (int r = 0; r < 16; r += 2) {
+      gelu_f32x2 v = {(own[r] + xb[r * 64]) + bcol, (own[r + 1] + xb[(r + 1) * 64]) + bcol};
+      if (MODE == 1) v = gelu_erf2(v);
+      my[((r & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v[0];
+      my[(((r + 1) & 3) + 8 * (r >> 2) + 4 * fh) * kEpiStride + fr] = (_Float16)v[1];
     }
     __builtin_amdgcn_wave_barrier();
     const int c0 = cblk * WN + pair * 32;

@@ -12,6 +12,8 @@ shapes = [(4096, 4096, 4096, 0),
           (65536, 1152, 384, 0), (65536, 1536, 384, 1), (65536, 384, 1536, 2), (65536, 384, 384, 2),          # MiniLM, 256 x 256 tokens
           (32768, 2304, 768, 0), (32768, 3072, 768, 1), (32768, 768, 3072, 2), (32768, 768, 768, 2),           # bge-base, 64 x 512 tokens
           (4096, 2304, 768, 0), (4096, 3072, 768, 1), (4096, 768, 3072, 2)]
+if len(sys.argv) > 4: shapes = [tuple(int(x) for x in sys.argv[i:i + 4]) for i in range(1, len(sys.argv) - 3, 4)]
+elif len(sys.argv) > 1: shapes = [x for x in shapes if x[0] == int(sys.argv[1]) and x[1] > 384]
 print("CRS_GEMM_BIG =", os.environ.get("CRS_GEMM_BIG", "(default 1)"))
 for m, n, k, mode in shapes:
     g = torch.Generator(device=dev); g.manual_seed(m + n + k)

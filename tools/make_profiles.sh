@@ -16,6 +16,13 @@ for w in $WL; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_$w -- python3 bench.py --workload $w --no-cpu-baseline > gpurun_out/${TAG}_stats_$w.log 2>&1 || { tail -5 gpurun_out/${TAG}_stats_$w.log; exit 1; }
   echo "stats $w done"
 done
+# encoder index-build workloads (bench line + kernel stats of the same command)
+for w in enc-minilm enc-bge; do
+  python3 bench.py --workload $w --steps 20 --warmup 3 > gpurun_out/${TAG}_bench_$w.json 2> gpurun_out/${TAG}_bench_$w.err || { tail -5 gpurun_out/${TAG}_bench_$w.err; exit 1; }
+  echo "bench $w done: $(cut -c100-240 gpurun_out/${TAG}_bench_$w.json)"
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 3 > gpurun_out/${TAG}_stats_$w.log 2>&1 || { tail -5 gpurun_out/${TAG}_stats_$w.log; exit 1; }
+  echo "stats $w done"
+done
 # PMC passes: counters only with --kernel-trace (one --pmc set per run)
 for w in c4; do
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -8,15 +8,15 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
 csv.field_size_limit(1 << 30)
-for w in ("c2", "c3", "c4", "c5"):
+for w in ("c2", "c3", "c4", "c5", "enc-minilm", "enc-bge"):
     src = os.path.join(go, f"{tag}_bench_{w}.json")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(pr, f"{tag}_bench_{w}.json"))
-for w in ("c2", "c3", "c4", "c5"):
+for w in ("c2", "c3", "c4", "c5", "enc-minilm", "enc-bge"):
     found = sorted(glob.glob(os.path.join(go, f"{tag}_stats_{w}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     for f in found[-1:]:   # gpurun merges every call's files into gpurun_out/: keep the newest run only
         rows = list(csv.reader(open(f)))
-        with open(os.path.join(pr, f"{tag}_{w}_kernel_stats.csv"), "w", newline="") as fh:
+        with open(os.path.join(pr, f"{tag}_{w.replace('-', '_')}_kernel_stats.csv"), "w", newline="") as fh:
             wr = csv.writer(fh)
             for r in rows[:26]:
                 r[0] = r[0][:160]
