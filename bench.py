@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="query batches in flight, one HIP stream each; a step is one batch on every stream")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="diagnostic: run the N > 1 step (process group, collectives, merge) with ONE rank -- RCCL on one card")
     ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the query batch size")
     ap.add_argument("--rows", type=int, default=0, help="diagnostic: override the corpus rows")
     ap.add_argument("--encode", default="auto", choices=("auto", "replicated", "sharded"),
@@ -206,9 +208,14 @@ def main():
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # multi: the distributed step (collectives + merge).  N > 1 always; --dist-single runs the same path on ONE rank
+    # (process group of world size 1): the RCCL calls, dtypes and graph / stream interplay of the N > 1 step, on one card
+    multi = world > 1 or args.dist_single
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29577"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CRS_DIST_BACKEND", "nccl")   # "gloo": functional rehearsal of N > 1 on one GPU
         if backend == "nccl":
@@ -218,7 +225,7 @@ def main():
 
     if args.workload in ENC_WORKLOADS:
         bench_encoder(args, torch, nat, dev, rank, world, dist)
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -238,11 +245,11 @@ def main():
     # --proxy-encode-shard): per batch 0.313 -> 0.261 ms at the 8-GPU shard size, 0.466 -> 0.414 at 4, 0.775 -> 0.749 at 2 --
     # at 2 GPUs the gain is less than a second collective is expected to cost
     want_shard = args.encode == "sharded" or (args.encode == "auto" and world >= 4)
-    shard_w = world if (strong and world > 1 and want_shard and qb % world == 0) else 1
-    if world == 1 and args.proxy_encode_shard > 1 and qb % args.proxy_encode_shard == 0:
+    shard_w = world if (strong and multi and want_shard and qb % world == 0) else 1
+    if not multi and args.proxy_encode_shard > 1 and qb % args.proxy_encode_shard == 0:
         shard_w = args.proxy_encode_shard
     q_loc = qb // shard_w                      # queries THIS rank encodes per batch
-    gather_q = (world > 1 and (not strong or shard_w > 1)) or (world == 1 and shard_w > 1)
+    gather_q = (multi and (not strong or shard_w > 1)) or (not multi and shard_w > 1)
     refine = not args.no_refine
     k_scan = max(k, K_SCAN) if refine else k
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
@@ -274,7 +281,7 @@ def main():
     ids_full = torch.from_numpy(ids_h).to(dev)
     lens_full = torch.from_numpy(mask_h.sum(1).astype(np.int32)).to(dev)
     q32 = enc.forward(ids_full, lens_full).clone()            # fp32 unit rows [qb, dim] (planting, diagnostics)
-    enc_lo = (rank if world > 1 else 0) * q_loc if shard_w > 1 else 0
+    enc_lo = (rank if multi else 0) * q_loc if shard_w > 1 else 0
     ids_d, lens_d = ids_full[enc_lo:enc_lo + q_loc].contiguous(), lens_full[enc_lo:enc_lo + q_loc].contiguous()
     # plant a near neighbour of every even query (50 % planted); strong: query 2p lives on rank p % world
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
@@ -300,9 +307,9 @@ def main():
             self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k_scan, rows), dtype=torch.uint8, device=dev)
             self.cand_s = torch.empty((nq_all, k_scan), dtype=torch.float32, device=dev)
             self.cand_i = torch.empty((nq_all, k_scan), dtype=torch.int64, device=dev)
-            self.wire = nat.WireBlock(nq_all, k, dev, world)     # this rank's (ids | scores) block + the gathered blocks
+            self.wire = nat.WireBlock(nq_all, k, dev, world, gather=multi)     # this rank's (ids | scores) block + the gathered blocks
             self.graphs = None
-            if world > 1:
+            if multi:
                 self.fin_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
                 self.fin_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
             if gather_q:
@@ -321,7 +328,7 @@ def main():
     def seg_search(c, do_refine=refine):       # all queries of the batch x this rank's shard -> this rank's wire block
         qa32 = c.q_all32 if gather_q else c.q_out
         if gather_q:
-            if world == 1:      # --proxy-encode-shard: the local queries tiled in place of the all-gather
+            if not multi:      # --proxy-encode-shard: the local queries tiled in place of the all-gather
                 c.q_all32.view(shard_w, q_loc, dim).copy_(c.q_out.unsqueeze(0).expand(shard_w, q_loc, dim))
             nat.queries_to_f16(qa32, slab_type, out=c.q_all16)
         qa16 = c.q_all16 if gather_q else c.q16
@@ -336,7 +343,7 @@ def main():
     def seg_merge(c):       # N > 1: the gathered wire blocks -> global top-k
         nat.merge_topk_wire(c.wire.gathered, world, nq_all, k, k, out_scores=c.fin_s, out_ids=c.fin_i)
 
-    if world == 1:
+    if not multi:
         segs = [lambda c: (seg_encode(c), seg_search(c))]
         exchanges = []
     elif strong and not gather_q:   # replicated queries: ONE collective per batch
@@ -355,10 +362,10 @@ def main():
                 seg(c)
             if j < len(exchanges):
                 exchanges[j](c)
-        return (c.fin_s, c.fin_i) if world > 1 else (c.wire.scores, c.wire.ids)
+        return (c.fin_s, c.fin_i) if multi else (c.wire.scores, c.wire.ids)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -406,7 +413,7 @@ def main():
     run(args.steps)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -418,7 +425,7 @@ def main():
     # fp32 rows of every shard (fp64 accumulation) -- catches quantisation loss as well as any mix-up of query
     # order, id bases, wire layout or merge.
     def gathered_queries():
-        if world > 1 and gather_q:
+        if multi and gather_q:
             qa = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(qa, ctxs[0].q_out.contiguous())
             return qa
@@ -430,7 +437,7 @@ def main():
     streams[0].synchronize()
     q_truth = gathered_queries()
     gt_s, gt_i = exact_topk_f64(torch, q_truth, shadow, rows, k, id_base)
-    if world > 1:
+    if multi:
         all_s = torch.empty((world * nq_all, k), dtype=torch.float64, device=dev)
         all_i = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(all_s, gt_s.contiguous()); dist.all_gather_into_tensor(all_i, gt_i.contiguous())
@@ -446,7 +453,7 @@ def main():
     c0 = ctxs[0]
     with torch.cuda.stream(streams[0]):
         seg_encode(c0)
-        if world > 1 and gather_q:
+        if multi and gather_q:
             dist.all_gather_into_tensor(c0.q_all32, c0.q_out)
         if refine:
             seg_search(c0, do_refine=False)
@@ -457,16 +464,16 @@ def main():
             qa16 = c0.q_all16 if gather_q else c0.q16
             qa32 = c0.q_all32 if gather_q else c0.q_out
             if gather_q:
-                if world == 1:
+                if not multi:
                     c0.q_all32.view(shard_w, q_loc, dim).copy_(c0.q_out.unsqueeze(0).expand(shard_w, q_loc, dim))
                 nat.queries_to_f16(qa32, slab_type, out=c0.q_all16)
             nat.cosine_topk(qa16, slab, rows, dim, max(k, K_SCAN), slab_type=slab_type, scales=scales, id_base=id_base,
                             workspace=c0.ws, out_scores=c0.cand_s, out_ids=c0.cand_i)
             nat.refine_f32(qa32, shadow, rows, id_base, c0.cand_i, k, out_scores=c0.wire.scores, out_ids=c0.wire.ids)
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(c0.wire.gathered, c0.wire.buf)
             seg_merge(c0)
-        oth_s, oth_i = ((c0.fin_s, c0.fin_i) if world > 1 else (c0.wire.scores, c0.wire.ids))
+        oth_s, oth_i = ((c0.fin_s, c0.fin_i) if multi else (c0.wire.scores, c0.wire.ids))
     streams[0].synchronize()
     recall_other = float(recall_rows(oth_i, gt_i).mean().item())
     err_other = float((oth_s.double() - gt_s).abs().max().item())
@@ -576,15 +583,15 @@ def main():
                        "slab": slab_kind, "refine_fp32": refine, "encoder_in_step": not args.scan_only,
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
                        "query_tokens": QUERY_TOKENS, "hip_graph": use_graph,
-                       "collectives_per_batch": len(exchanges),
+                       "collectives_per_batch": len(exchanges), "dist_single_rank": bool(multi and world == 1),
                        "query_encode": ("replicated" if not gather_q else ("per-rank queries (weak scaling)" if not strong else
-                                        f"sharded: {q_loc} of {qb} queries per rank" + (" [single-GPU proxy: tiled instead of gathered]" if world == 1 else ""))),
+                                        f"sharded: {q_loc} of {qb} queries per rank" + (" [single-GPU proxy: tiled instead of gathered]" if not multi else ""))),
                        "recall_at_10_vs_fp32": recall_report, "check_ok": check_ok,
                        "index_build_s_per_gpu": round(t_build, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         ok_t = torch.tensor([1 if check_ok else 0], device=dev)
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
         check_ok = bool(ok_t.item())

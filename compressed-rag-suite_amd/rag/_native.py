@@ -222,7 +222,7 @@ class WireBlock:
     [ids int64 [nq, k] | scores fp32 [nq, k] | pad].  `.ids` / `.scores` are views into `.buf`, so the
     search kernels write the block in place and `buf` is what the all-gather sends."""
 
-    def __init__(self, nq: int, k: int, device, world: int = 1):
+    def __init__(self, nq: int, k: int, device, world: int = 1, gather: bool = False):
         import torch
         lib = load()
         self.nq, self.k, self.world = nq, k, world
@@ -231,7 +231,7 @@ class WireBlock:
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.ids = self.buf[:off].view(torch.int64).view(nq, k)
         self.scores = self.buf[off:off + nq * k * 4].view(torch.float32).view(nq, k)
-        self.gathered = torch.zeros(world * self.nbytes, dtype=torch.uint8, device=device) if world > 1 else None
+        self.gathered = torch.zeros(world * self.nbytes, dtype=torch.uint8, device=device) if (world > 1 or gather) else None
 
 
 def merge_topk_wire(gathered, nlists: int, nq: int, k_in: int, k_out: int, out_scores=None, out_ids=None):

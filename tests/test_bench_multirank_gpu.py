@@ -62,3 +62,31 @@ def test_int8_two_rank_strong_recall_is_one_after_refine(cuda):
     c = d["config"]
     assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
     assert c["recall_at_10_vs_fp32"]["scan_only_no_refine"] < 1.0      # int8 alone does flip ranks: the refine is what fixes it
+
+
+def _run_single_rccl(extra):
+    """The N > 1 step on ONE rank over the real RCCL backend (process group of world size 1): the collectives' dtypes
+    (uint8 wire blocks, fp32 embeddings), their interplay with graph replay and side streams, and the wire merge."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env.pop("CRS_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dist-single", "--steps", "4", "--warmup", "1", "--streams", "3",
+           "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_rank_rccl_strong_step(cuda):
+    d = _run_single_rccl(["--workload", "c4", "--rows", "600000"])
+    c = d["config"]
+    assert c["dist_single_rank"] is True and c["collectives_per_batch"] == 1 and c["hip_graph"] is True
+    assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
+
+
+def test_single_rank_rccl_weak_step_gathers_queries(cuda):
+    d = _run_single_rccl(["--workload", "c2", "--scaling", "weak"])
+    c = d["config"]
+    assert c["dist_single_rank"] is True and c["collectives_per_batch"] == 2
+    assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
