@@ -11,8 +11,9 @@ One query BATCH through the retrieve path, everything resident in HBM:
      of the shard (the ranking the reference's fp32 ChromaDB collection gives), best k = 10 written
      straight into this rank's wire block
   -> (N > 1) ONE RCCL all-gather of the wire blocks + k-way merge on every rank.
-A STEP is one such batch on each of the S in-flight HIP streams (S = --streams), so the timed region is
-steady state whatever --steps is; queries per step = S x Qb.
+A STEP is S such batches in flight (S = --streams, each with its own buffers), so the timed region is steady state
+whatever --steps is; queries per step = S x Qb.  --lanes: every batch wholly on its own HIP stream ("batch"), or encoder
+forwards on encoder lane(s) and searches on search lane(s), tied by events ("split": C4-class scans; see main()).
 
 Workloads (BASELINE.json configs; --workload):
   c4  10M x 384 fp16 corpus, global 64-query batches, k=10      (default: the configuration the metric is quoted on)
@@ -179,6 +180,13 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="query batches in flight, one HIP stream each; a step is one batch on every stream")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--lanes", default="auto", choices=("auto", "split", "batch"),
+                    help="stream layout of the in-flight batches: 'batch' = every batch wholly on its own stream; 'split' = encoder "
+                         "forwards on encoder lane(s), searches on search lane(s), tied by events (with the encoder's kernels sized to "
+                         "sit beside the scan's workgroups: CRS_PANEL_KC=128 CRS_ENC_QKVATTN=0); auto = split for MiniLM-class encoders "
+                         "over scans of >= 512 MB per batch (C4), else batch")
+    ap.add_argument("--enc-lanes", type=int, default=0, help="--lanes split: streams that run encoder forwards (0: 1, or 2 from 4 GPUs on)")
+    ap.add_argument("--search-lanes", type=int, default=0, help="--lanes split: streams that run searches (0: 2, or 1 from 4 GPUs on)")
     ap.add_argument("--dist-single", action="store_true",
                     help="diagnostic: run the N > 1 step (process group, collectives, merge) with ONE rank -- RCCL on one card")
     ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the query batch size")
@@ -254,6 +262,17 @@ def main():
     k_scan = max(k, K_SCAN) if refine else k
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
     pd = nat.padded_dim(dim, slab_type)
+    # Lane layout (see the comment at the batch loop).  'split' only pays when the scan is long against the encoder chain
+    # AND the encoder's kernels can run beside the scan's workgroups (2 x 48 KB of a CU's 160 KB of LDS are taken): the
+    # MiniLM-class query encoder has such a form (K walked in 128-column chunks, QKV projection and attention as separate
+    # launches: <= 48 KB each); measured per 64-query batch, same call, one lane per batch -> split: C4 1.40 - 1.42 ->
+    # 1.31 - 1.39 ms, one rank of a 4 / 8-GPU step 0.470 -> 0.462 / 0.265 -> 0.252 ms; bge-base (C5 / C3) and C2 lose
+    # with it (tools/ab_lanes*.sh).
+    scan_bytes = rows * pd * (1 if slab_type == nat.SLAB_I8 else 2)
+    pipelined = args.lanes == "split" or (args.lanes == "auto" and enc_name == "minilm" and scan_bytes >= (512 << 20))
+    if pipelined:
+        os.environ.setdefault("CRS_PANEL_KC", "128")
+        os.environ.setdefault("CRS_ENC_QKVATTN", "0")
 
     # ---- index build (untimed): synthetic embeddings -> slab shard (+ fp32 shadow) in HBM through the product path
     slab = torch.empty((rows, pd), dtype=torch.int8 if slab_type == nat.SLAB_I8 else torch.float16, device=dev)
@@ -343,51 +362,89 @@ def main():
     def seg_merge(c):       # N > 1: the gathered wire blocks -> global top-k
         nat.merge_topk_wire(c.wire.gathered, world, nq_all, k, k, out_scores=c.fin_s, out_ids=c.fin_i)
 
-    if not multi:
-        segs = [lambda c: (seg_encode(c), seg_search(c))]
-        exchanges = []
-    elif strong and not gather_q:   # replicated queries: ONE collective per batch
-        segs = [lambda c: (seg_encode(c), seg_search(c)), seg_merge]
-        exchanges = [lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)]
-    else:                   # queries encoded in shards (or weak scaling: per-rank queries): embeddings gathered first
-        segs = [seg_encode, seg_search, seg_merge]
-        exchanges = [lambda c: dist.all_gather_into_tensor(c.q_all32, c.q_out),
-                     lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)]
-
-    def batch(c):
-        for j, seg in enumerate(segs):
-            if c.graphs is not None:
-                c.graphs[j].replay()
-            else:
-                seg(c)
-            if j < len(exchanges):
-                exchanges[j](c)
-        return (c.fin_s, c.fin_i) if multi else (c.wire.scores, c.wire.ids)
+    # segments of a batch, in order, each with the collective that follows it (N > 1) and the lane it runs on
+    # ("E": encoder lane, "S": search lane)
+    segs = [seg_encode, seg_search] + ([seg_merge] if multi else [])
+    lanes = ["E", "S", "S"][: len(segs)]
+    exchanges = [None] * len(segs)
+    if multi and gather_q:  # queries encoded in shards (or weak scaling: per-rank queries): embeddings gathered first
+        exchanges[0] = lambda c: dist.all_gather_into_tensor(c.q_all32, c.q_out)
+    if multi:               # the ONE exchange of a sharded search: every rank's wire block
+        exchanges[1] = lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)
+    n_exchanges = sum(1 for e in exchanges if e is not None)
 
     def sync():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Throughput mode: S independent batches in flight, each on its own stream with its own buffers.  For N > 1 the
-    # RCCL collective between the segments is launched eagerly (those of different batches are serialised on the
-    # process group's own stream; every rank issues them in the same order).
-    n_streams = max(1, args.streams)
+    # Throughput mode: S batches in flight, each with its own buffers (Ctx).  The GPU runs a process's streams on four
+    # hardware queues; a query-encoder forward is a chain of 38 dependent launches of a few microseconds each (latency,
+    # not work), a scan is one kernel that wants every byte of HBM bandwidth.  Round 1 / early round 2 gave every batch
+    # its own stream -- encoder chain, scan, merge, refine in one lane -- so a lane spent a third of its time inside an
+    # encoder chain and the scans of the other lanes did not always cover it (C4 batch 1.38 - 1.41 ms for a 1.28 ms scan).
+    # Now the lanes have ROLES: encoder forwards of upcoming batches run on the encoder lane(s), searches alternate
+    # between the search lanes (one's merge / refine tail under the other's scan), tied together by events per Ctx;
+    # the same kernels, the same work per batch, nothing skipped.  --lanes batch restores one lane per batch.
+    # For N > 1 the RCCL collectives between the segments are launched eagerly in batch order (every rank issues them in
+    # the same order; they are serialised on the process group's own stream).
+    n_ctx = max(1, args.streams)
     use_graph = not args.no_graph
-    ctxs = [Ctx() for _ in range(n_streams)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    ctxs = [Ctx() for _ in range(n_ctx)]
+    if pipelined:
+        # measured (tools/ab_lanes.sh): the 7.7 GB scan of the whole corpus wants two search lanes (one's merge / refine tail
+        # under the other's scan) and is fed by one encoder lane; shards of <= 5 M rows (N >= 2) are short enough that two
+        # encoder lanes are needed to keep ONE search lane busy
+        short_scans = scan_bytes < (6 << 30)
+        n_enc = args.enc_lanes if args.enc_lanes > 0 else (2 if short_scans else 1)
+        n_srch = args.search_lanes if args.search_lanes > 0 else (1 if short_scans else 2)
+        enc_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_enc)]
+        srch_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_srch)]
+    else:
+        n_enc = n_srch = n_ctx
+        enc_lanes = srch_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)]
+    for c in ctxs:
+        c.ev_enc, c.ev_done = torch.cuda.Event(), torch.cuda.Event()
+    issued = [0]
+
+    def batch(c):
+        """Issue one batch: encode on an encoder lane, search (+ exchange + merge) on a search lane."""
+        b = issued[0]
+        issued[0] += 1
+        lane = {"E": enc_lanes[b % n_enc], "S": srch_lanes[b % n_srch]}
+        prev = None
+        for j, seg in enumerate(segs):
+            st = lane[lanes[j]]
+            with torch.cuda.stream(st):
+                if j == 0:
+                    st.wait_event(c.ev_done)          # the previous batch that used this Ctx is through (no-op before its first use)
+                elif st is not prev:
+                    st.wait_event(c.ev_enc)           # lane change: the encoder lane's output (and its collective) is complete
+                if c.graphs is not None:
+                    c.graphs[j].replay()
+                else:
+                    seg(c)
+                if exchanges[j] is not None:
+                    exchanges[j](c)
+                if j == 0:
+                    c.ev_enc.record(st)
+                if j == len(segs) - 1:
+                    c.ev_done.record(st)
+            prev = st
+        return (c.fin_s, c.fin_i) if multi else (c.wire.scores, c.wire.ids)
+
     torch.cuda.synchronize()
-    for c, st in zip(ctxs, streams):
-        with torch.cuda.stream(st):
-            for _ in range(2):
-                batch(c)
-        st.synchronize()
+    for c in ctxs:
+        for _ in range(2):
+            batch(c)
+        torch.cuda.synchronize()
         if use_graph:
             # thread_local: with N > 1 the process group's watchdog thread polls events while we capture;
             # only this thread's calls belong to the capture.  If a capture fails anyway, run eagerly.
             try:
                 gl = []
-                for seg in segs:
+                for j, seg in enumerate(segs):
+                    st = (enc_lanes if lanes[j] == "E" else srch_lanes)[0]
                     g_ = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
                         seg(c)
@@ -403,9 +460,8 @@ def main():
 
     def run(n_steps):
         for _ in range(n_steps):
-            for c, st in zip(ctxs, streams):
-                with torch.cuda.stream(st):
-                    batch(c)
+            for c in ctxs:
+                batch(c)
 
     run(args.warmup)
     sync()
@@ -417,7 +473,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    q_per_step = nq_all * n_streams
+    q_per_step = nq_all * n_ctx
     ms_step = dt / args.steps * 1e3
     qps = q_per_step * args.steps / dt
 
@@ -431,10 +487,9 @@ def main():
             return qa
         return ctxs[0].q_all32 if gather_q else ctxs[0].q_out
 
-    with torch.cuda.stream(streams[0]):
-        fin_s, fin_i = batch(ctxs[0])
-        fin_s, fin_i = fin_s.clone(), fin_i.clone()
-    streams[0].synchronize()
+    fin_s, fin_i = batch(ctxs[0])           # (issues on its lanes)
+    torch.cuda.synchronize()
+    fin_s, fin_i = fin_s.clone(), fin_i.clone()
     q_truth = gathered_queries()
     gt_s, gt_i = exact_topk_f64(torch, q_truth, shadow, rows, k, id_base)
     if multi:
@@ -451,7 +506,7 @@ def main():
     score_err = float((fin_s.double() - gt_s).abs().max().item())
     # the other mode, for the record (one untimed eager batch): plain fp16/int8 scan with k' = k, or the refined one
     c0 = ctxs[0]
-    with torch.cuda.stream(streams[0]):
+    with torch.cuda.stream(srch_lanes[0]):
         seg_encode(c0)
         if multi and gather_q:
             dist.all_gather_into_tensor(c0.q_all32, c0.q_out)
@@ -474,7 +529,7 @@ def main():
             dist.all_gather_into_tensor(c0.wire.gathered, c0.wire.buf)
             seg_merge(c0)
         oth_s, oth_i = ((c0.fin_s, c0.fin_i) if multi else (c0.wire.scores, c0.wire.ids))
-    streams[0].synchronize()
+    torch.cuda.synchronize()
     recall_other = float(recall_rows(oth_i, gt_i).mean().item())
     err_other = float((oth_s.double() - gt_s).abs().max().item())
     tol = 1e-5 if refine else (5e-3 if slab_type == nat.SLAB_I8 else 1e-3)
@@ -578,12 +633,12 @@ def main():
             "dtype": "f16 x f16 -> f32" if slab_type == nat.SLAB_F16 else "i8 x i16(f16 query) -> i32 -> f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "corpus_rows": corpus_rows, "rows_per_gpu": rows, "dim": dim,
-                       "queries_per_batch": nq_all, "batches_per_step": n_streams, "queries_per_step": q_per_step,
-                       "ms_per_batch": round(ms_step / n_streams, 5), "top_k": k, "k_scan": k_scan,
+                       "queries_per_batch": nq_all, "batches_per_step": n_ctx, "queries_per_step": q_per_step,
+                       "ms_per_batch": round(ms_step / n_ctx, 5), "lanes": (f"{n_enc} encoder + {n_srch} search (encoder kernels <= 48 KB of LDS)" if pipelined else "one per batch"), "top_k": k, "k_scan": k_scan,
                        "slab": slab_kind, "refine_fp32": refine, "encoder_in_step": not args.scan_only,
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
                        "query_tokens": QUERY_TOKENS, "hip_graph": use_graph,
-                       "collectives_per_batch": len(exchanges), "dist_single_rank": bool(multi and world == 1),
+                       "collectives_per_batch": n_exchanges, "dist_single_rank": bool(multi and world == 1),
                        "query_encode": ("replicated" if not gather_q else ("per-rank queries (weak scaling)" if not strong else
                                         f"sharded: {q_loc} of {qb} queries per rank" + (" [single-GPU proxy: tiled instead of gathered]" if not multi else ""))),
                        "recall_at_10_vs_fp32": recall_report, "check_ok": check_ok,

@@ -29,7 +29,8 @@ def _run(extra, port):
 
 
 def test_two_rank_strong_step_is_exact_vs_fp32(cuda):
-    d = _run(["--workload", "c4", "--rows", "600000", "--encode", "sharded"], 29533)    # (auto shards from 4 GPUs on)
+    d = _run(["--workload", "c4", "--rows", "600000", "--encode", "sharded", "--lanes", "split"], 29533)   # (auto: from 4 GPUs on / 512 MB scans)
+    assert d["config"]["lanes"].startswith("2 encoder + 1 search")
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert c["corpus_rows"] == 600_000 and c["rows_per_gpu"] == 300_000 and c["queries_per_batch"] == 64
@@ -44,6 +45,7 @@ def test_two_rank_strong_step_is_exact_vs_fp32(cuda):
 def test_two_rank_strong_step_replicated_encode_is_one_collective(cuda):
     d = _run(["--workload", "c4", "--rows", "600000"], 29536)                           # N = 2 default: replicated
     c = d["config"]
+    assert c["lanes"] == "one per batch"                                                 # auto: a 230 MB shard is too short to split
     assert c["collectives_per_batch"] == 1 and c["query_encode"] == "replicated"
     assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
 
@@ -79,8 +81,9 @@ def _run_single_rccl(extra):
 
 
 def test_single_rank_rccl_strong_step(cuda):
-    d = _run_single_rccl(["--workload", "c4", "--rows", "600000"])
+    d = _run_single_rccl(["--workload", "c4", "--rows", "1400000"])                      # 1.07 GB scan: auto picks the split lanes
     c = d["config"]
+    assert c["lanes"].startswith("2 encoder + 1 search")
     assert c["dist_single_rank"] is True and c["collectives_per_batch"] == 1 and c["hip_graph"] is True
     assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
 
