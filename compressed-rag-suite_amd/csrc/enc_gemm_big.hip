@@ -206,12 +206,17 @@ int launch_big_mode(const _Float16* a, const _Float16* w, const float* bias, con
 // residual epilogue at N = 768 (three column blocks = 384 workgroups = one and a half waves of the chip: 582 against
 // 667 for the 128 x 128 kernel's 1536 workgroups), and MiniLM's K = 384 shapes (six k-steps: the row-streaming kernel's
 // resident weights win, 733 / 541 against 419 / 439 with 256 x 128 tiles).  CRS_GEMM_BIG=0 disables it (A/B runs).
+// It is taken from 128 workgroups on (CRS_GEMM_BIG_MIN_WGS): at 4096 tokens of bge-base (C3's query batch) 144 / 192
+// workgroups of 256 x 256 beat the row-streaming kernel's 144 (QKV 42.0 -> 35.9 us, FFN-up 57.4 -> 41.5); at 2048 tokens
+// (72 / 96 workgroups) they lose (25.7 -> 31.5, 33.1 -> 36.6).
 int gemm_big_block_n(int m, int n, int k, int mode) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("CRS_GEMM_BIG"); on = (e && e[0] == '0') ? 0 : 1; }
   if (!on || mode == 2 || k % 64 != 0 || k < 512 || n % 256 != 0) return 0;
   const long wgs = (long)(n / 256) * ((m + GM - 1) / GM);
-  return wgs >= 256 ? 256 : 0;
+  static long min_wgs = -1;
+  if (min_wgs < 0) { const char* e = getenv("CRS_GEMM_BIG_MIN_WGS"); min_wgs = e ? atol(e) : 128; }
+  return wgs >= min_wgs ? 256 : 0;
 }
 
 int gemm_big_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k, int mode,
