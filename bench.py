@@ -125,26 +125,36 @@ def bench_encoder(args, torch, nat, dev, rank, world, dist):
     ids_h[:, 0], ids_h[:, -1] = 101, 102
     ids_d = torch.from_numpy(ids_h).to(dev)
     lens_d = torch.full((batch,), seq, dtype=torch.int32, device=dev)
-    out = torch.empty((batch, shape.hidden), dtype=torch.float32, device=dev)
-    ws = torch.empty(enc.workspace_bytes(batch, seq), dtype=torch.uint8, device=dev)
+    # F forwards in flight (--enc-inflight), each on its own stream with its own output / workspace: a step is F batches
+    nfl = max(1, args.enc_inflight)
+    outs = [torch.empty((batch, shape.hidden), dtype=torch.float32, device=dev) for _ in range(nfl)]
+    wss = [torch.empty(enc.workspace_bytes(batch, seq), dtype=torch.uint8, device=dev) for _ in range(nfl)]
+    sts = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        for o_, w_, s_ in zip(outs, wss, sts):
+            with torch.cuda.stream(s_):
+                enc.forward(ids_d, lens_d, out=o_, workspace=w_)
+
+    torch.cuda.synchronize()
     for _ in range(max(1, args.warmup)):
-        enc.forward(ids_d, lens_d, out=out, workspace=ws)
+        step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        enc.forward(ids_d, lens_d, out=out, workspace=ws)
+        step()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    batch *= nfl
     tokens = batch * seq
     h, f, nl = shape.hidden, shape.ffn, shape.layers
     flops = tokens * nl * (2 * (4 * h * h + 2 * h * f)) + nl * 4 * seq * h * tokens   # projections + QK^T + PV
@@ -157,7 +167,8 @@ def bench_encoder(args, torch, nat, dev, rank, world, dist):
             "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 x f16 -> f32", "data": "synthetic",
             "config": {"workload": args.workload, "encoder": ("all-MiniLM-L6-v2" if arch_name == "minilm" else "bge-base-en-v1.5")
-                       + " shape, seeded random weights", "chunks_per_step_per_gpu": batch, "tokens_per_chunk": seq},
+                       + " shape, seeded random weights", "chunks_per_step_per_gpu": batch, "tokens_per_chunk": seq,
+                       "batches_in_flight": nfl},
             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TF["f16"], "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_PEAK_TF["f16"], 4), "traffic": None,
                          "kernel": "whole forward (see profiles/r02_enc_*_kernel_stats.csv for the per-kernel split)",
@@ -180,6 +191,8 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="query batches in flight, one HIP stream each; a step is one batch on every stream")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--enc-inflight", type=int, default=2,
+                    help="enc-* workloads: forwards in flight, one stream each (a step = that many batches; 2 = what EmbeddingModel.embed does)")
     ap.add_argument("--lanes", default="auto", choices=("auto", "split", "batch"),
                     help="stream layout of the in-flight batches: 'batch' = every batch wholly on its own stream; 'split' = encoder "
                          "forwards on encoder lane(s), searches on search lane(s), tied by events (with the encoder's kernels sized to "

@@ -202,12 +202,30 @@ class EmbeddingModel:
             return self.model.forward(ids, lens, normalize=bool(self.normalize), out=out)
         # longest first, like SentenceTransformer.encode: least padding per batch
         order = sorted(range(n), key=lambda i: -len(texts[i]))
-        for lo in range(0, n, self.batch_size):
+        # Two batches in flight on two side streams: the forward's HBM-bound phases (LayerNorm epilogues: a quarter of a
+        # MiniLM layer at index-build size) of one batch run under the matrix phases of the other (+ 3-5 % tokens/s,
+        # bench.py --workload enc-* --enc-inflight 2); host-side padding of the next batch overlaps too.
+        cur = torch.cuda.current_stream(out.device)
+        lanes = [torch.cuda.Stream(device=out.device) for _ in range(2)]
+        lane_ws = [None, None]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        for b, lo in enumerate(range(0, n, self.batch_size)):
             sel = order[lo: lo + self.batch_size]
             ids, lens = pad_batch([token_ids[i] for i in sel], getattr(self.tokenizer, "pad_id", 0),
                                   short_steps=tuple(st for st in (16, 32, 64) if st <= self.shape.max_seq))
-            emb = self.model.forward(ids, lens, normalize=bool(self.normalize))
-            out[torch.as_tensor(sel, device=out.device)] = emb
+            st = lanes[b & 1]
+            with torch.cuda.stream(st):
+                if b < 2:
+                    st.wait_event(ready)        # `out` (and anything the caller queued) before the first write
+                need = self.model.workspace_bytes(int(ids.shape[0]), int(ids.shape[1]))
+                if lane_ws[b & 1] is None or lane_ws[b & 1].numel() < need:     # the encoder's own scratch is shared:
+                    lane_ws[b & 1] = torch.empty(need, dtype=torch.uint8, device=out.device)   # concurrent forwards need one each
+                emb = self.model.forward(ids, lens, normalize=bool(self.normalize), workspace=lane_ws[b & 1])
+                out[torch.as_tensor(sel, device=out.device)] = emb
+        for st in lanes:
+            out.record_stream(st)
+            cur.wait_stream(st)
         return out
 
     def embed(self, texts: Union[str, List[str]], show_progress: bool = False) -> np.ndarray:

@@ -34,3 +34,23 @@ def test_embedding_model_from_local_dir_matches_oracle(cuda, tmp_path, pooling):
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
     one = em.embed(TEXTS[0])
     assert one.shape == (1, 64) and float((one[0] * got[0]).sum()) > 1 - 1e-5
+
+
+def test_many_batches_on_two_lanes_equal_one_batch(cuda, tmp_path):
+    """embed() of more texts than batch_size runs consecutive batches on two side streams (own workspace each) and
+    scatters them back into input order: same embeddings as ONE batch of all texts (up to padding-length effects: none
+    for a masked encoder), whatever the text lengths."""
+    from _modeldir import write_model_dir
+    from rag.embedding import EmbeddingModel
+    d = str(tmp_path / "model")
+    write_model_dir(d, pooling="mean", bert_prefix=False, sbert_lower=False, tok_lower=True, tokenizer_json=True, seed=9)
+    rng = np.random.default_rng(3)
+    words = ["vector", "store", "cosine", "retrieval", "chunk", "query", "index", "fox", "dog", "paper"]
+    texts = [" ".join(rng.choice(words, size=int(rng.integers(1, 40)))) for _ in range(37)]
+    many = EmbeddingModel({"model_name": d, "batch_size": 4, "normalize": True}).embed(texts)
+    one = EmbeddingModel({"model_name": d, "batch_size": 64, "normalize": True}).embed(texts)
+    assert many.shape == one.shape == (37, 64)
+    cos = (many * one).sum(1)
+    assert float(cos.min()) > 1 - 1e-5, float(cos.min())
+    again = EmbeddingModel({"model_name": d, "batch_size": 4, "normalize": True}).embed(texts)
+    assert np.array_equal(many, again)          # no race between the lanes: bit-identical on a re-run
