@@ -198,8 +198,8 @@ def main():
                          "forwards on encoder lane(s), searches on search lane(s), tied by events (with the encoder's kernels sized to "
                          "sit beside the scan's workgroups: CRS_PANEL_KC=128 CRS_ENC_QKVATTN=0); auto = split for MiniLM-class encoders "
                          "over scans of >= 512 MB per batch (C4), else batch")
-    ap.add_argument("--enc-lanes", type=int, default=0, help="--lanes split: streams that run encoder forwards (0: 1, or 2 from 4 GPUs on)")
-    ap.add_argument("--search-lanes", type=int, default=0, help="--lanes split: streams that run searches (0: 2, or 1 from 4 GPUs on)")
+    ap.add_argument("--enc-lanes", type=int, default=0, help="--lanes split: streams that run encoder forwards (0: 2)")
+    ap.add_argument("--search-lanes", type=int, default=0, help="--lanes split: streams that run searches (0: 1)")
     ap.add_argument("--dist-single", action="store_true",
                     help="diagnostic: run the N > 1 step (process group, collectives, merge) with ONE rank -- RCCL on one card")
     ap.add_argument("--queries", type=int, default=0, help="diagnostic: override the query batch size")
@@ -405,12 +405,13 @@ def main():
     use_graph = not args.no_graph
     ctxs = [Ctx() for _ in range(n_ctx)]
     if pipelined:
-        # measured (tools/ab_lanes.sh): the 7.7 GB scan of the whole corpus wants two search lanes (one's merge / refine tail
-        # under the other's scan) and is fed by one encoder lane; shards of <= 5 M rows (N >= 2) are short enough that two
-        # encoder lanes are needed to keep ONE search lane busy
-        short_scans = scan_bytes < (6 << 30)
-        n_enc = args.enc_lanes if args.enc_lanes > 0 else (2 if short_scans else 1)
-        n_srch = args.search_lanes if args.search_lanes > 0 else (1 if short_scans else 2)
+        # measured (tools/ab_lanes.sh): two encoder lanes feed ONE search lane at every shard size (one encoder lane starves
+        # scans of <= 2.5 M rows: 0.41 against 0.25 ms per batch at 1.25 M).  On the whole 10 M-row corpus a second search
+        # lane (one scan's merge / refine tail under the next scan) is worth another 1 - 2 %, but then consecutive scans
+        # overlap and a per-kernel duration -- the roofline's denominator, the rocprof kernel average -- stops meaning
+        # "one scan"; with one search lane the scans run one after another (1.30 ms in the trace against 1.27 - 1.28 isolated).
+        n_enc = args.enc_lanes if args.enc_lanes > 0 else 2
+        n_srch = args.search_lanes if args.search_lanes > 0 else 1
         enc_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_enc)]
         srch_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_srch)]
     else:
