@@ -130,11 +130,31 @@ __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float
   }
   __syncthreads();   // all fragment reads done: the ring becomes the fp32 tile
 
-  // ---- two 64-row halves through LDS, then the row LayerNorm (8-byte form)
+  // ---- two 64-row halves through LDS, then the row LayerNorm (8-byte form).  A wave normalises rows wave, wave + 8, ...
+  // of a half; the residual values of ALL its eight rows are requested before the half's accumulators go to LDS, so the
+  // epilogue pays one global round trip per half.  (As first written the loads sat inside the row loop: sixteen dependent
+  // round trips per workgroup, ~29 us per round of workgroups with the matrix pipe idle -- "no epilogue traffic" took
+  // 58 us off a 107 us out-proj launch, and staggering the workgroups did not, which is what gave it away.)
   float* tile = reinterpret_cast<float*>(r2sm);
   constexpr int ts = H + 4;
+  float2 bi[3], gg[3], bb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = 128 * i + 2 * lane;
+    bi[i] = bias ? *reinterpret_cast<const float2*>(bias + c) : float2{0.f, 0.f};
+    gg[i] = *reinterpret_cast<const float2*>(g + c);
+    bb[i] = *reinterpret_cast<const float2*>(b + c);
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    float2 re[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int gr = m0 + half * 64 + wave + 8 * j;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        re[j][i] = gr < M ? *reinterpret_cast<const float2*>(residual + (size_t)gr * H + 128 * i + 2 * lane) : float2{0.f, 0.f};
+    }
     if ((rb >> 1) == half) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -144,40 +164,39 @@ __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float
       }
     }
     __syncthreads();
-    for (int row = wave; row < 64; row += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = wave + 8 * j;
       const int gr = m0 + half * 64 + row;
-      if (gr >= M) break;
-      float v[3][2];
-      float s = 0.f;
+      if (gr < M) {                                  // wave-uniform
+        float v[3][2];
+        float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int c = 128 * i + 2 * lane;
-        const float2 t2 = *reinterpret_cast<const float2*>(&tile[row * ts + c]);
-        const float2 bi = bias ? *reinterpret_cast<const float2*>(bias + c) : float2{0.f, 0.f};
-        const float2 re = *reinterpret_cast<const float2*>(residual + (size_t)gr * H + c);
-        v[i][0] = (t2.x + bi.x) + re.x;
-        v[i][1] = (t2.y + bi.y) + re.y;
-        s += v[i][0] + v[i][1];
-      }
-      const float mean = wave_sum_rl(s) / H;
-      float q = 0.f;
+        for (int i = 0; i < 3; ++i) {
+          const float2 t2 = *reinterpret_cast<const float2*>(&tile[row * ts + 128 * i + 2 * lane]);
+          v[i][0] = (t2.x + bi[i].x) + re[j][i].x;
+          v[i][1] = (t2.y + bi[i].y) + re[j][i].y;
+          s += v[i][0] + v[i][1];
+        }
+        const float mean = wave_sum_rl(s) / H;
+        float q = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
-        q += d0 * d0 + d1 * d1;
-      }
-      const float rstd = 1.0f / sqrtf(wave_sum_rl(q) / H + eps);
+        for (int i = 0; i < 3; ++i) {
+          const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+          q += d0 * d0 + d1 * d1;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum_rl(q) / H + eps);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int c = 128 * i + 2 * lane;
-        const float2 gg = *reinterpret_cast<const float2*>(g + c), bb = *reinterpret_cast<const float2*>(b + c);
-        float2 o;
-        o.x = (v[i][0] - mean) * rstd * gg.x + bb.x;
-        o.y = (v[i][1] - mean) * rstd * gg.y + bb.y;
-        *reinterpret_cast<float2*>(x32 + (size_t)gr * H + c) = o;
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 hh = {(_Float16)o.x, (_Float16)o.y};
-        *reinterpret_cast<h2*>(x16 + (size_t)gr * H + c) = hh;
+        for (int i = 0; i < 3; ++i) {
+          const int c = 128 * i + 2 * lane;
+          float2 o;
+          o.x = (v[i][0] - mean) * rstd * gg[i].x + bb[i].x;
+          o.y = (v[i][1] - mean) * rstd * gg[i].y + bb[i].y;
+          *reinterpret_cast<float2*>(x32 + (size_t)gr * H + c) = o;
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          const h2 hh = {(_Float16)o.x, (_Float16)o.y};
+          *reinterpret_cast<h2*>(x16 + (size_t)gr * H + c) = hh;
+        }
       }
     }
     __syncthreads();   // the tile is rewritten by the other half
