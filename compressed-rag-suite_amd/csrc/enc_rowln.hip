@@ -137,23 +137,35 @@ __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float
   // 58 us off a 107 us out-proj launch, and staggering the workgroups did not, which is what gave it away.)
   float* tile = reinterpret_cast<float*>(r2sm);
   constexpr int ts = H + 4;
-  float2 bi[3], gg[3], bb[3];
+  // Row LayerNorm with HALF a wave per row: lane l of a half-wave holds 12 consecutive columns (48 bytes) of its row, so a
+  // wave instruction advances two rows -- 16-byte loads and stores (five stores per row pair instead of twelve), five
+  // cross-lane steps per reduction instead of six.  Same two-pass fp32 statistics, eps inside the sqrt.
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int hl = lane & 31, hw = lane >> 5;
+  const int c0 = 12 * hl;
+  f32x4 bi[3], gg[3], bb[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int c = 128 * i + 2 * lane;
-    bi[i] = bias ? *reinterpret_cast<const float2*>(bias + c) : float2{0.f, 0.f};
-    gg[i] = *reinterpret_cast<const float2*>(g + c);
-    bb[i] = *reinterpret_cast<const float2*>(b + c);
+    bi[i] = bias ? *reinterpret_cast<const f32x4*>(bias + c0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gg[i] = *reinterpret_cast<const f32x4*>(g + c0 + 4 * i);
+    bb[i] = *reinterpret_cast<const f32x4*>(b + c0 + 4 * i);
   }
+  auto half_sum = [](float x) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+  };
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    float2 re[8][3];
+    f32x4 re[4][3];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int gr = m0 + half * 64 + wave + 8 * j;
+    for (int j = 0; j < 4; ++j) {
+      const int gr = m0 + half * 64 + wave + 8 * (2 * j + hw);
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        re[j][i] = gr < M ? *reinterpret_cast<const float2*>(residual + (size_t)gr * H + 128 * i + 2 * lane) : float2{0.f, 0.f};
+        re[j][i] = gr < M ? *reinterpret_cast<const f32x4*>(residual + (size_t)gr * H + c0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if ((rb >> 1) == half) {
 #pragma unroll
@@ -165,38 +177,37 @@ __global__ __launch_bounds__(kRlThreads, 1) void gemm_rowln2_kernel(const _Float
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int row = wave + 8 * j;
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave + 8 * (2 * j + hw);
       const int gr = m0 + half * 64 + row;
-      if (gr < M) {                                  // wave-uniform
-        float v[3][2];
-        float s = 0.f;
+      f32x4 v[3];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&tile[row * ts + c0 + 4 * i]);
+        v[i] = (t4 + bi[i]) + re[j][i];
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      }
+      const float mean = half_sum(s) / H;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const f32x4 d = v[i] - mean;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+      const float rstd = 1.0f / sqrtf(half_sum(q) / H + eps);
+      if (gr < M) {                                  // per half-wave
+        f32x4 o[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const float2 t2 = *reinterpret_cast<const float2*>(&tile[row * ts + 128 * i + 2 * lane]);
-          v[i][0] = (t2.x + bi[i].x) + re[j][i].x;
-          v[i][1] = (t2.y + bi[i].y) + re[j][i].y;
-          s += v[i][0] + v[i][1];
+          o[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+          *reinterpret_cast<f32x4*>(x32 + (size_t)gr * H + c0 + 4 * i) = o[i];
         }
-        const float mean = wave_sum_rl(s) / H;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
-          q += d0 * d0 + d1 * d1;
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum_rl(q) / H + eps);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int c = 128 * i + 2 * lane;
-          float2 o;
-          o.x = (v[i][0] - mean) * rstd * gg[i].x + bb[i].x;
-          o.y = (v[i][1] - mean) * rstd * gg[i].y + bb[i].y;
-          *reinterpret_cast<float2*>(x32 + (size_t)gr * H + c) = o;
-          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-          const h2 hh = {(_Float16)o.x, (_Float16)o.y};
-          *reinterpret_cast<h2*>(x16 + (size_t)gr * H + c) = hh;
-        }
+        const h8 lo = {(_Float16)o[0][0], (_Float16)o[0][1], (_Float16)o[0][2], (_Float16)o[0][3],
+                       (_Float16)o[1][0], (_Float16)o[1][1], (_Float16)o[1][2], (_Float16)o[1][3]};
+        const h4 hi = {(_Float16)o[2][0], (_Float16)o[2][1], (_Float16)o[2][2], (_Float16)o[2][3]};
+        *reinterpret_cast<h8*>(x16 + (size_t)gr * H + c0) = lo;
+        *reinterpret_cast<h4*>(x16 + (size_t)gr * H + c0 + 8) = hi;
       }
     }
     __syncthreads();   // the tile is rewritten by the other half
