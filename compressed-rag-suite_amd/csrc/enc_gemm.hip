@@ -117,6 +117,22 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
   // then each thread finishes 4 (fp32 out) or 8 (fp16 out) consecutive columns of a row with
   // 16-byte coalesced loads / stores.  Lane holds column (lane & 31), rows (r&3) + 8(r>>2) + 4(lane>>5).
   float* tile = reinterpret_cast<float*>(smem);
+  // mode 2: the residual values this thread will add (16 x 16 bytes) are requested BEFORE the accumulators go through
+  // LDS -- one global round trip per workgroup.  (As first written the load sat inside the store loop: load, wait, store,
+  // sixteen dependent round trips per thread with the matrix pipe idle; same finding as in enc_rowln.hip.)
+  constexpr int kIt2 = BM * (BN / 4) / kThreads;   // 16
+  const int c4 = (tid % (BN / 4)) * 4, gc2 = n0 + c4;          // this thread's column group is the same in every pass
+  const bool cols_in = gc2 + 3 < N;
+  f32x4 rs[kIt2];
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 2) {
+    if (bias && cols_in) b4 = *reinterpret_cast<const f32x4*>(bias + gc2);
+#pragma unroll
+    for (int it = 0; it < kIt2; ++it) {
+      const int gr = m0 + (tid + it * kThreads) / (BN / 4);
+      rs[it] = (gr < M && cols_in) ? *reinterpret_cast<const f32x4*>(residual + (size_t)gr * N + gc2) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -129,19 +145,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_kernel(const _Float16* _
   __syncthreads();
   if (MODE == 2) {
     float* o = reinterpret_cast<float*>(out);
-    for (int id = tid; id < BM * (BN / 4); id += kThreads) {
-      const int row = id / (BN / 4), c4 = (id % (BN / 4)) * 4;
-      const int gr = m0 + row, gc = n0 + c4;
-      if (gr >= M || gc >= N) continue;
+#pragma unroll
+    for (int it = 0; it < kIt2; ++it) {
+      const int row = (tid + it * kThreads) / (BN / 4);
+      const int gr = m0 + row;
+      if (gr >= M || gc2 >= N) continue;
       const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * BN + c4);
-      const size_t at = (size_t)gr * N + gc;
-      if (gc + 3 < N) {
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(residual + at);
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (bias) b = *reinterpret_cast<const f32x4*>(bias + gc);
-        *reinterpret_cast<f32x4*>(o + at) = v + b + rs;
+      const size_t at = (size_t)gr * N + gc2;
+      if (cols_in) {
+        *reinterpret_cast<f32x4*>(o + at) = v + b4 + rs[it];
       } else {
-        for (int e = 0; e < 4 && gc + e < N; ++e) o[at + e] = v[e] + (bias ? bias[gc + e] : 0.f) + residual[at + e];
+        for (int e = 0; e < 4 && gc2 + e < N; ++e) o[at + e] = v[e] + (bias ? bias[gc2 + e] : 0.f) + residual[at + e];
       }
     }
   } else {
