@@ -55,6 +55,11 @@ struct Plan {
 int partial_width(int k) { return (crs::scan_share_tau() && k <= 16) ? 16 : k; }
 size_t tau_bytes(int nq) { return align_up16((size_t)nq * 4); }
 
+bool tb_long_chain() {   // CRS_SCAN_LONG_CHAIN=0: 16 < k <= 32 on long streams back on the threshold kernels (A/B, tests)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRS_SCAN_LONG_CHAIN"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
 bool tb_enabled() {   // CRS_SCAN_TB=0: always use the threshold/compaction kernel for <= 64 queries (A/B runs, tests)
   static int v = -1;
   if (v < 0) { const char* e = getenv("CRS_SCAN_TB"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -116,8 +121,13 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
       } else if (k <= 16) {
         p->tb_slots = crs::scan_wide_slots(k);
         p->kp = p->tb_slots;
+      } else if (tb_long_chain() && (p->i8_tb ? crs::scan_i8_long_chain_slots(p->pdim, k) : crs::scan_tb_long_chain_slots(p->pdim, p->tb_nw, k)) > 0) {
+        // 16 < k <= 32 on a long stream: the same kernels with a 32-slot chain instead of the threshold kernels
+        // (CRS_SCAN_LONG_CHAIN=0 restores those; k > 32 stays on them: scan_tb.hip has the measurement)
+        p->tb_slots = p->i8_tb ? crs::scan_i8_long_chain_slots(p->pdim, k) : crs::scan_tb_long_chain_slots(p->pdim, p->tb_nw, k);
+        p->kp = p->tb_slots;
       } else {
-        continue;                            // k > 16 on a long stream: the threshold kernels
+        continue;                            // the threshold kernels
       }
     }
     break;
@@ -328,7 +338,7 @@ int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type
   if (p.w1_qg) snprintf(name, sizeof name, "scan_w2_kernel<%d> (%d queries/workgroup, dump)", p.pdim, p.w1_qg);
   else if (p.wide_nw) snprintf(name, sizeof name, "scan_wide_kernel<%d,%d,%d>", p.pdim, p.wide_nw, crs::scan_wide_slots(k));
   else if (p.tb_nw) snprintf(name, sizeof name, "scan_tb_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, p.tb_nw, p.tb_slots);
-  else if (slab_type == CRS_SLAB_I8) snprintf(name, sizeof name, "scan_i8_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32, p.i8_tb ? p.tb_slots : -1);
+  else if (slab_type == CRS_SLAB_I8) snprintf(name, sizeof name, "scan_i8_kernel<%d,%d,%d,%d>", p.pdim, p.tile_rows, (p.i8_tb || k <= 16) ? 16 : 32, p.i8_tb ? p.tb_slots : -1);
   else snprintf(name, sizeof name, "scan_f16_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
   snprintf(buf, cap, "%s streams=%d qblocks=%d kp=%d + merge%s", name, p.nwg, p.nqb, p.kp, p.group_best ? " + refine" : "");
   return CRS_OK;

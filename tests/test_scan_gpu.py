@@ -117,3 +117,36 @@ def test_c2_full_size(cuda):
     for r in range(64):
         assert scan_ref.recall_at_k(gi[r], ri[r]) >= 0.9
     assert np.mean([scan_ref.recall_at_k(gi[r], ri[r]) for r in range(64)]) > 0.995
+
+
+@pytest.mark.parametrize("n,d,nq,k,kind", [(700_000, 384, 64, 20, "f16"), (700_000, 384, 7, 32, "f16"), (400_000, 768, 64, 32, "i8"),
+                                            (600_000, 128, 64, 17, "f16")])
+def test_long_chain_matches_oracle_and_threshold_kernels(cuda, n, d, nq, k, kind):
+    """16 < k <= 32 on streams too long for the dump form: scan_tb / scan_i8 with a 32-slot chain.  Checked against the
+    oracle; test_scan_classic_gpu.py re-runs this module on the threshold kernels (CRS_SCAN_TB=0)."""
+    import torch
+    from oracle import scan_ref
+    from rag import _native as nat
+    c = scan_ref.synth_corpus(n, d, seed=31)
+    q = scan_ref.synth_queries(c, nq, seed=32)
+    st = nat.SLAB_I8 if kind == "i8" else nat.SLAB_F16
+    pd = nat.padded_dim(d, st)
+    slab = torch.zeros((n, pd), dtype=torch.int8 if kind == "i8" else torch.float16, device=cuda)
+    scales = torch.zeros(n, dtype=torch.float32, device=cuda) if kind == "i8" else None
+    nat.slab_append_f32(torch.from_numpy(c).to(cuda), slab, 0, st, scales=scales)
+    q16 = nat.queries_to_f16(torch.from_numpy(q).to(cuda), st)
+    import os
+    if os.environ.get("CRS_SCAN_TB", "1") != "0" and os.environ.get("CRS_SCAN_LONG_CHAIN", "1") != "0":
+        assert ",32>" in nat.scan_plan_describe(nq, d, k, n, slab_type=st)             # the 32-slot chain plan
+    s, i = nat.cosine_topk(q16, slab, n, d, k, slab_type=st, scales=scales)
+    torch.cuda.synchronize()
+    if kind == "f16":
+        full = scan_ref.full_scores_f64(q16.cpu().numpy(), slab.cpu().numpy())
+        check_topk(s.cpu().numpy(), i.cpu().numpy(), full, k)
+    else:
+        qd = scan_ref.dequantized_queries(q16.cpu().numpy())
+        full = scan_ref.full_scores_f64(qd, slab.cpu().numpy(), scales.cpu().numpy())
+        got = i.cpu().numpy()
+        for r in range(nq):
+            assert np.abs(full[r, got[r]] - s[r].cpu().numpy()).max() < 1e-5
+            assert full[r, got[r]].min() >= np.sort(full[r])[-k] - 1e-6
