@@ -55,7 +55,7 @@ struct Plan {
 int partial_width(int k) { return (crs::scan_share_tau() && k <= 16) ? 16 : k; }
 size_t tau_bytes(int nq) { return align_up16((size_t)nq * 4); }
 
-bool tb_long_chain() {   // CRS_SCAN_LONG_CHAIN=0: 16 < k <= 32 on long streams back on the threshold kernels (A/B, tests)
+bool tb_long_chain() {   // CRS_SCAN_LONG_CHAIN=0: 16 < k <= 64 on long streams back on the threshold kernels (A/B, tests)
   static int v = -1;
   if (v < 0) { const char* e = getenv("CRS_SCAN_LONG_CHAIN"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
@@ -122,8 +122,8 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
         p->tb_slots = crs::scan_wide_slots(k);
         p->kp = p->tb_slots;
       } else if (tb_long_chain() && (p->i8_tb ? crs::scan_i8_long_chain_slots(p->pdim, k) : crs::scan_tb_long_chain_slots(p->pdim, p->tb_nw, k)) > 0) {
-        // 16 < k <= 32 on a long stream: the same kernels with a 32-slot chain instead of the threshold kernels
-        // (CRS_SCAN_LONG_CHAIN=0 restores those; k > 32 stays on them: scan_tb.hip has the measurement)
+        // 16 < k <= 64 on a long stream: the same kernels with a 32- / 64-slot chain instead of the threshold kernels,
+        // where that chain fits the register file (CRS_SCAN_LONG_CHAIN=0 restores the threshold kernels)
         p->tb_slots = p->i8_tb ? crs::scan_i8_long_chain_slots(p->pdim, k) : crs::scan_tb_long_chain_slots(p->pdim, p->tb_nw, k);
         p->kp = p->tb_slots;
       } else {

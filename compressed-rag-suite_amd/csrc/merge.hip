@@ -78,13 +78,22 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   const float* qs = scores + (size_t)q * q_stride;
   const IdT* qi = ids + (size_t)q * q_stride;
   const bool contig = (list_stride == (size_t)k_in) && (id_list_stride == (size_t)k_in);
+  // Which entry a thread visits in its v-th step.  Plain striding (entry = v) gives thread t the SAME slot t % k_in of every
+  // list whenever k_in divides 256 -- and the lists arrive sorted, so a few threads own every list's best entries, the
+  // k-th largest "bucket maximum" below is then the maximum of a bucket of 4th-best entries, far too low a bar, the LDS
+  // list overflows and the exact-but-slow fallback runs (k = 32 over 512 lists: 210-250 us instead of ~ 15).  Rotating the
+  // slot by the pass number (a bijection inside each list, which lies within one pass when k_in | 256) gives every thread
+  // all slots in turn.
+  const bool rotate = (kThreads % k_in) == 0 && k_in > 1;
+  auto entry_of = [&](int v) { return rotate ? (v - v % k_in) + ((v % k_in) + v / kThreads) % k_in : v; };
 #define CRS_FOR_EACH_ENTRY(BODY)                                                         \
   for (int e0 = tid; e0 < m; e0 += 8 * kThreads) {                                       \
     float s_[8];                                                                         \
     IdT id_[8];                                                                          \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
-      const int e = e0 + u * kThreads;                                                   \
-      const bool in = e < m;                                                             \
+      const int v_ = e0 + u * kThreads;                                                  \
+      const bool in = v_ < m;                                                            \
+      const int e = in ? entry_of(v_) : 0;                                               \
       size_t at = 0, ati = 0;                                                            \
       if (in) {                                                                          \
         at = contig ? (size_t)e : (size_t)(e / k_in) * list_stride + (e % k_in);         \
@@ -117,8 +126,9 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   if (cached) {
 #pragma unroll
     for (int u = 0; u < kRegE; ++u) {
-      const int e = tid + u * kThreads;
-      const bool in = e < m;
+      const int v = tid + u * kThreads;
+      const bool in = v < m;
+      const int e = in ? entry_of(v) : 0;
       cs[u] = in ? qs[e] : kNegInf;
       ci[u] = in ? qi[e] : (IdT)-1;
     }

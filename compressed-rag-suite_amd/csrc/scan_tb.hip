@@ -260,12 +260,12 @@ int launch_tb_k(const ScanArgs& a, int slots, hipStream_t stream) {
     case 4: return launch_tb<D, TR, NW, 4>(a, stream);
     case 10: return launch_tb<D, TR, NW, 10>(a, stream);
     case 16: return launch_tb<D, TR, NW, 16>(a, stream);
-    // 16 < k <= 32 on long streams: a 32-slot chain (5 VALU per slot and tile, still under the tile's memory time; its 64
-    // registers fit beside the query fragments of every row length at two waves per SIMD).  10 M x 384, 64 queries, k = 17 /
-    // 32: scan 2.36 / 2.13 ms on the threshold kernels -> 1.23 / 1.24 ms, whole search 2.09 / 2.16 -> 1.31 / 1.49.  A
-    // 64-slot chain (built, measured) scans in 1.84 ms against 2.70 but its 64 re-opened tiles per query make merge +
-    // refine cost more than that saves (search 3.46 against 2.76 ms), and it spills from 512-element rows on: not kept.
+    // 16 < k <= 64 on long streams: a 32- or 64-slot chain (5 VALU per slot and tile, still under the tile's memory time)
+    // instead of the threshold kernels.  32 slots (64 registers) fit beside the query fragments of every row length at two
+    // waves per SIMD; 64 slots only for 256- / 384-element rows (they spill from 512 on).  10 M x 384, 64 queries, k = 17 / 32:
+    // scan 2.36 / 2.13 ms on the threshold kernels -> 1.23 ms, whole search 2.09 / 2.16 -> 1.31 / 1.32.
     case 32: if constexpr (NW == 4) return launch_tb<D, TR, NW, 32>(a, stream); else return -1;
+    case 64: if constexpr (NW == 4 && (D == 256 || D == 384)) return launch_tb<D, TR, NW, 64>(a, stream); else return -1;
     default: return -1;
   }
 }
@@ -298,8 +298,12 @@ int scan_tb_wg_per_cu(int pdim, int nw) {
   }
 }
 
-// chain length for 16 < k <= 32 on long streams (0: none -- the threshold kernels take the search)
-int scan_tb_long_chain_slots(int pdim, int nw, int k) { return (nw == 4 && k > 16 && k <= 32) ? 32 : 0; }
+// chain length for 16 < k <= 64 on long streams (0: none -- the threshold kernels take the search)
+int scan_tb_long_chain_slots(int pdim, int nw, int k) {
+  if (nw != 4 || k <= 16 || k > 64) return 0;
+  if (k <= 32) return 32;
+  return (pdim == 256 || pdim == 384) ? 64 : 0;
+}
 
 // slots = 0: dump mode (kp = tiles per stream); else chain mode with that many slots (kp = slots)
 int scan_launch_tb(const ScanArgs& a, int pdim, int nw, int slots, hipStream_t stream) {

@@ -39,7 +39,7 @@ def _make(cuda, n, d, nq, slab_type, seed):
     ("c3", 1_000_000, 768, 256, 10, "f16"),
     ("c5-shard", 1_250_000, 768, 64, 10, "i8"),
     ("c4-k40", 1_250_000, 384, 16, 40, "f16"),
-    # 16 < k <= 32 on long streams: the 32-slot chain of the tile-best kernels (k = 40 above stays on the threshold kernels)
+    # 16 < k <= 64 on long streams: the 32- / 64-slot chains of the tile-best kernels (k = 40 above: the 64-slot one)
     ("c4-shard-k17", 1_250_000, 384, 64, 17, "f16"),
     ("c4-shard-k32", 1_250_000, 384, 64, 32, "f16"),
     ("c5-shard-k24", 1_250_000, 768, 64, 24, "i8"),
