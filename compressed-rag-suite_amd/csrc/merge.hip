@@ -73,27 +73,34 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = nlists * k_in;
   // candidate e = (list e / k_in, slot e % k_in) lives at list*list_stride + q*q_stride + slot
-  // (== e when a query's lists are contiguous).  Threads walk e = tid, tid+256, ... eight at a
+  // (== e when a query's lists are contiguous).  Threads walk the entries in passes (below), eight passes at a
   // time with all loads issued before any use, so L2 latency is paid once per batch of 8.
   const float* qs = scores + (size_t)q * q_stride;
   const IdT* qi = ids + (size_t)q * q_stride;
   const bool contig = (list_stride == (size_t)k_in) && (id_list_stride == (size_t)k_in);
-  // Which entry a thread visits in its v-th step.  Plain striding (entry = v) gives thread t the SAME slot t % k_in of every
-  // list whenever k_in divides 256 -- and the lists arrive sorted, so a few threads own every list's best entries, the
-  // k-th largest "bucket maximum" below is then the maximum of a bucket of 4th-best entries, far too low a bar, the LDS
-  // list overflows and the exact-but-slow fallback runs (k = 32 over 512 lists: 210-250 us instead of ~ 15).  Rotating the
-  // slot by the pass number (a bijection inside each list, which lies within one pass when k_in | 256) gives every thread
-  // all slots in turn.
-  const bool rotate = (kThreads % k_in) == 0 && k_in > 1;
-  auto entry_of = [&](int v) { return rotate ? (v - v % k_in) + ((v % k_in) + v / kThreads) % k_in : v; };
+  // Which entry a thread visits in pass p.  Plain striding (entry = tid + 256 p) gives thread t the SAME slot t % k_in of
+  // every list whenever k_in divides 256 (a few slots when it shares a factor) -- and the lists arrive sorted, so a few
+  // threads own every list's best entries, the k-th largest "bucket maximum" below is then the maximum of a bucket of
+  // 4th-best entries, far too low a bar, the LDS list overflows and the exact-but-slow fallback runs (k = 32 over 512
+  // lists: 210-250 us instead of ~ 15).  So a pass covers WHOLE lists (C = the largest multiple of k_in <= 256 entries;
+  // threads >= C sit the pass out) and the slot is rotated by the pass number -- a bijection inside each list: every
+  // thread meets all slots in turn.
+  const bool rotate = k_in > 1 && k_in <= kThreads;
+  const int C = rotate ? (kThreads / k_in) * k_in : kThreads;          // entries per pass
+  auto entry_of = [&](int p) {                                          // -1: none for this thread in pass p
+    if (tid >= C) return -1;
+    const int v = p * C + tid;
+    if (v >= m) return -1;
+    return rotate ? (v - v % k_in) + ((v % k_in) + p) % k_in : v;
+  };
+  const int n_pass = (m + C - 1) / C;
 #define CRS_FOR_EACH_ENTRY(BODY)                                                         \
-  for (int e0 = tid; e0 < m; e0 += 8 * kThreads) {                                       \
+  for (int p0 = 0; p0 < n_pass; p0 += 8) {                                               \
     float s_[8];                                                                         \
     IdT id_[8];                                                                          \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
-      const int v_ = e0 + u * kThreads;                                                  \
-      const bool in = v_ < m;                                                            \
-      const int e = in ? entry_of(v_) : 0;                                               \
+      const int e = (p0 + u < n_pass) ? entry_of(p0 + u) : -1;                           \
+      const bool in = e >= 0;                                                            \
       size_t at = 0, ati = 0;                                                            \
       if (in) {                                                                          \
         at = contig ? (size_t)e : (size_t)(e / k_in) * list_stride + (e % k_in);         \
@@ -119,18 +126,16 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   // candidate set crosses the memory system exactly once (the generic path below walks it twice in
   // batches of 8 and was bound by those serial round trips).
   constexpr int kRegE = 32;
-  const bool cached = contig && m <= kRegE * kThreads;
+  const bool cached = contig && n_pass <= kRegE;
   float cs[kRegE];
   IdT ci[kRegE];
   float best = kNegInf;
   if (cached) {
 #pragma unroll
     for (int u = 0; u < kRegE; ++u) {
-      const int v = tid + u * kThreads;
-      const bool in = v < m;
-      const int e = in ? entry_of(v) : 0;
-      cs[u] = in ? qs[e] : kNegInf;
-      ci[u] = in ? qi[e] : (IdT)-1;
+      const int e = (u < n_pass) ? entry_of(u) : -1;
+      cs[u] = e >= 0 ? qs[e] : kNegInf;
+      ci[u] = e >= 0 ? qi[e] : (IdT)-1;
     }
 #pragma unroll
     for (int u = 0; u < kRegE; ++u) best = fmaxf(best, (ci[u] >= 0) ? cs[u] : kNegInf);

@@ -266,6 +266,7 @@ int launch_tb_k(const ScanArgs& a, int slots, hipStream_t stream) {
     // scan 2.36 / 2.13 ms on the threshold kernels -> 1.23 ms, whole search 2.09 / 2.16 -> 1.31 / 1.32.
     case 32: if constexpr (NW == 4) return launch_tb<D, TR, NW, 32>(a, stream); else return -1;
     case 64: if constexpr (NW == 4 && (D == 256 || D == 384)) return launch_tb<D, TR, NW, 64>(a, stream); else return -1;
+    case 48: if constexpr (NW == 4 && D >= 512 && D <= 768) return launch_tb<D, TR, NW, 48>(a, stream); else return -1;   // k <= 48: the reference's 2 k = 40
     default: return -1;
   }
 }
@@ -302,7 +303,8 @@ int scan_tb_wg_per_cu(int pdim, int nw) {
 int scan_tb_long_chain_slots(int pdim, int nw, int k) {
   if (nw != 4 || k <= 16 || k > 64) return 0;
   if (k <= 32) return 32;
-  return (pdim == 256 || pdim == 384) ? 64 : 0;
+  if (pdim == 256 || pdim == 384) return 64;
+  return (k <= 48 && pdim >= 512 && pdim <= 768) ? 48 : 0;     // 512 .. 768-element rows: 48 slots still fit (64 spill)
 }
 
 // slots = 0: dump mode (kp = tiles per stream); else chain mode with that many slots (kp = slots)
