@@ -297,7 +297,7 @@ int launch_i8(const ScanArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// slots: -1 classic, 0 dump, 4 / 10 / 16 / 32 chain
+// slots: -1 classic, 0 dump, 4 / 10 / 16 / 32 / 48 chain
 template <int D>
 int launch_i8_d(const ScanArgs& a, int slots, hipStream_t stream) {
   switch (slots) {
@@ -306,6 +306,7 @@ int launch_i8_d(const ScanArgs& a, int slots, hipStream_t stream) {
     case 10: return launch_i8<D, 32, 16, 10>(a, stream);
     case 16: return launch_i8<D, 32, 16, 16>(a, stream);
     case 32: return launch_i8<D, 32, 16, 32>(a, stream);   // 16 < k <= 32 on long streams (a 64-slot chain spills at these row lengths)
+    case 48: if constexpr (D <= 768) return launch_i8<D, 32, 16, 48>(a, stream); else return -1;   // k <= 48 (the reference's 2 k = 40)
     default: break;
   }
   if (a.k <= 16) return launch_i8<D, 32, 16, -1>(a, stream);
@@ -316,7 +317,7 @@ int launch_i8_d(const ScanArgs& a, int slots, hipStream_t stream) {
 
 int scan_i8_tile_rows() { return 32; }
 
-int scan_i8_long_chain_slots(int pdim, int k) { return (k > 16 && k <= 32) ? 32 : 0; }
+int scan_i8_long_chain_slots(int pdim, int k) { return (k <= 16 || k > 48) ? 0 : k <= 32 ? 32 : (pdim <= 768 ? 48 : 0); }
 
 int scan_launch_i8(const ScanArgs& a, int pdim, int slots, hipStream_t stream) {
   switch (pdim) {

@@ -121,7 +121,7 @@ def test_c2_full_size(cuda):
 
 @pytest.mark.parametrize("n,d,nq,k,kind", [(700_000, 384, 64, 20, "f16"), (700_000, 384, 7, 32, "f16"), (400_000, 768, 64, 32, "i8"),
                                             (600_000, 128, 64, 17, "f16"), (700_000, 384, 33, 40, "f16"), (500_000, 256, 64, 64, "f16"),
-                                            (400_000, 768, 64, 40, "f16")])
+                                            (400_000, 768, 64, 40, "f16"), (400_000, 768, 64, 40, "i8")])
 def test_long_chain_matches_oracle_and_threshold_kernels(cuda, n, d, nq, k, kind):
     """16 < k <= 64 on streams too long for the dump form: scan_tb / scan_i8 with a 32- / 48- / 64-slot chain.  Checked against the
     oracle; test_scan_classic_gpu.py re-runs this module on the threshold kernels (CRS_SCAN_TB=0)."""
@@ -138,7 +138,7 @@ def test_long_chain_matches_oracle_and_threshold_kernels(cuda, n, d, nq, k, kind
     q16 = nat.queries_to_f16(torch.from_numpy(q).to(cuda), st)
     import os
     if os.environ.get("CRS_SCAN_TB", "1") != "0" and os.environ.get("CRS_SCAN_LONG_CHAIN", "1") != "0":
-        want = ",32>" if k <= 32 else (",64>" if d <= 384 else ",48>")
+        want = ",32>" if k <= 32 else (",64>" if (d <= 384 and kind == "f16") else ",48>")
         assert want in nat.scan_plan_describe(nq, d, k, n, slab_type=st)                # the long-chain plan
     s, i = nat.cosine_topk(q16, slab, n, d, k, slab_type=st, scales=scales)
     torch.cuda.synchronize()
