@@ -150,7 +150,7 @@ int set_error(int code, const char* msg) {  // shared with enc_capi.hip
 extern "C" {
 
 const char* crs_last_error(void) { return g_err; }
-int crs_abi_version(void) { return 2; }
+int crs_abi_version(void) { return 3; }
 int crs_row_elems(int dim, int slab_type) {
   if (dim <= 0) return 0;
   const int g = slab_type == CRS_SLAB_I8 ? 256 : 128;
@@ -159,14 +159,14 @@ int crs_row_elems(int dim, int slab_type) {
 int crs_padded_dim(int dim) { return crs_row_elems(dim, CRS_SLAB_F16); }
 
 int crs_slab_append_f32(const float* emb_dev, int64_t n, int dim, int slab_type, void* slab_dev,
-                        float* scales_dev, float* shadow_f32_dev, int64_t row0, void* stream) {
+                        float* scales_dev, float* shadow_f32_dev, int64_t row0, float* row_err_max_dev, void* stream) {
   if (n < 0 || dim <= 0 || dim > 1024 || row0 < 0) return fail(CRS_EINVAL, "bad n/dim/row0");
   if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
   if (n == 0) return CRS_OK;
   if (!emb_dev || !slab_dev) return fail(CRS_EINVAL, "null pointer");
   if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
   const int e = crs::slab_append_launch(emb_dev, n, dim, crs_row_elems(dim, slab_type), slab_type, slab_dev,
-                                        scales_dev, shadow_f32_dev, row0, (hipStream_t)stream);
+                                        scales_dev, shadow_f32_dev, row0, row_err_max_dev, (hipStream_t)stream);
   return e ? hip_fail((hipError_t)e, "slab_append") : CRS_OK;
 }
 
@@ -312,6 +312,59 @@ int crs_refine_f32(const float* q32_dev, int nq, int dim, const float* shadow_de
   const int e = crs::refine_f32_launch(q32_dev, nq, dim, shadow_dev, n_rows, id_base, cand_ids_dev, k_in, k_out,
                                        out_scores_dev, out_ids_dev, (hipStream_t)stream);
   return e ? hip_fail((hipError_t)e, "refine_f32 launch") : CRS_OK;
+}
+
+// exactness workspace: [threshold f32 [nq] | counter i32 [nq] | row lists i64 [nq, cap]]
+static size_t exact_lists_off(int nq) { return 2 * align_up((size_t)nq * 4, 256); }
+size_t crs_exact_workspace_bytes(int nq, int cap) {
+  return (nq > 0 && cap > 0) ? exact_lists_off(nq) + (size_t)nq * cap * 8 : 0;
+}
+float crs_exact_row_error_bound(int dim, int slab_type) { return crs::exact_err_rows_bound(dim, slab_type); }
+
+static int exact_args_ok(int nq, int dim, int slab_type, int cap, size_t ws_bytes, const void* ws) {
+  if (slab_type != CRS_SLAB_F16 && slab_type != CRS_SLAB_I8) return fail(CRS_EINVAL, "bad slab_type");
+  if (nq <= 0 || dim <= 0 || dim > 1024) return fail(CRS_EINVAL, "bad nq/dim");
+  if (cap < 64 || cap > CRS_EXACT_MAX_CAP) return fail(CRS_EINVAL, "cap must be in 64..CRS_EXACT_MAX_CAP");
+  if (!ws || ((uintptr_t)ws & 15)) return fail(CRS_EINVAL, "exactness workspace must be a 16-byte aligned device pointer");
+  if (ws_bytes < crs_exact_workspace_bytes(nq, cap)) return fail(CRS_ENOSPC, "exactness workspace too small");
+  return CRS_OK;
+}
+
+int crs_refine_f32_cert(const float* q32_dev, const void* q16_dev, int nq, int dim, int slab_type, const float* shadow_dev,
+                        int64_t n_rows, int64_t id_base, const int64_t* cand_ids_dev, const float* cand_scores_dev, int k_in,
+                        int k_out, float row_err_max, float* out_scores_dev, int64_t* out_ids_dev, int32_t* status_dev,
+                        void* exact_ws_dev, size_t exact_ws_bytes, int cap, void* stream) {
+  int rc = exact_args_ok(nq, dim, slab_type, cap, exact_ws_bytes, exact_ws_dev);
+  if (rc) return rc;
+  if (n_rows <= 0 || k_out <= 0 || k_in < k_out || k_in > CRS_MAX_K) return fail(CRS_EINVAL, "bad sizes (1 <= k_out <= k_in <= CRS_MAX_K)");
+  if (!q32_dev || !q16_dev || !shadow_dev || !cand_ids_dev || !cand_scores_dev || !out_scores_dev || !out_ids_dev || !status_dev)
+    return fail(CRS_EINVAL, "null pointer");
+  if (!(row_err_max >= 0.f)) row_err_max = crs::exact_err_rows_bound(dim, slab_type);   // untracked (or NaN): the analytic worst case
+  char* ws = reinterpret_cast<char*>(exact_ws_dev);
+  const int e = crs::refine_cert_launch(q32_dev, reinterpret_cast<const _Float16*>(q16_dev), nq, dim, crs_row_elems(dim, slab_type),
+                                        slab_type, shadow_dev, n_rows, id_base, cand_ids_dev, cand_scores_dev, k_in, k_out, row_err_max,
+                                        out_scores_dev, out_ids_dev, status_dev, reinterpret_cast<float*>(ws),
+                                        reinterpret_cast<int*>(ws + align_up((size_t)nq * 4, 256)), (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "refine_f32_cert launch") : CRS_OK;
+}
+
+int crs_escalate_exact(const float* q32_dev, const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,
+                       const float* scales_dev, const float* shadow_dev, int64_t n_rows, int64_t id_base, int k_out,
+                       float* out_scores_dev, int64_t* out_ids_dev, int32_t* status_dev, void* exact_ws_dev,
+                       size_t exact_ws_bytes, int cap, void* stream) {
+  int rc = exact_args_ok(nq, dim, slab_type, cap, exact_ws_bytes, exact_ws_dev);
+  if (rc) return rc;
+  if (n_rows <= 0 || n_rows > 0x7fffffffLL - 64 || k_out <= 0 || k_out > CRS_MAX_K) return fail(CRS_EINVAL, "bad sizes");
+  if (!q32_dev || !q16_dev || !slab_dev || !shadow_dev || !out_scores_dev || !out_ids_dev || !status_dev) return fail(CRS_EINVAL, "null pointer");
+  if (slab_type == CRS_SLAB_I8 && !scales_dev) return fail(CRS_EINVAL, "int8 slab needs scales");
+  if (((uintptr_t)q16_dev | (uintptr_t)slab_dev) & 15) return fail(CRS_EINVAL, "q/slab must be 16-byte aligned");
+  char* ws = reinterpret_cast<char*>(exact_ws_dev);
+  const int e = crs::escalate_launch(q32_dev, reinterpret_cast<const _Float16*>(q16_dev), nq, dim, crs_row_elems(dim, slab_type), slab_type,
+                                     slab_dev, scales_dev, shadow_dev, n_rows, id_base, k_out, out_scores_dev, out_ids_dev, status_dev,
+                                     reinterpret_cast<const float*>(ws), reinterpret_cast<int*>(ws + align_up((size_t)nq * 4, 256)),
+                                     reinterpret_cast<int64_t*>(ws + exact_lists_off(nq)), cap, device_cus(), (hipStream_t)stream);
+  if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
+  return e ? hip_fail((hipError_t)e, "escalate launch") : CRS_OK;
 }
 
 size_t crs_wire_scores_offset(int nq, int k) { return (nq > 0 && k > 0) ? (size_t)nq * k * 8 : 0; }

@@ -32,7 +32,8 @@ template <bool I8>
 __global__ __launch_bounds__(256) void slab_append_kernel(const float* __restrict__ emb, int64_t n,
                                                          int dim, int pdim, void* __restrict__ slab,
                                                          float* __restrict__ scales,
-                                                         float* __restrict__ shadow, int64_t row0) {
+                                                         float* __restrict__ shadow, int64_t row0,
+                                                         float* __restrict__ row_err_max) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void slab_append_kernel(const float* __restric
   ss = wave_sum(ss);
   const float inv_den = fmaxf(sqrtf(ss), 1e-12f);
   const int64_t dr = row0 + r;
+  float err2 = 0.f;
   if (I8) {
     float amax = 0.f;
     for (int c = lane; c < dim; c += 64) amax = fmaxf(amax, fabsf(src[c] / inv_den));
@@ -59,6 +61,8 @@ __global__ __launch_bounds__(256) void slab_append_kernel(const float* __restric
       qv = fminf(fmaxf(qv, -127.f), 127.f);
       dst[c] = (int8_t)qv;
       if (shadow && c < dim) shadow[dr * dim + c] = x;
+      const float d = x - qv * sc;            // the row as the scan sees it: int8 * scale
+      err2 = fmaf(d, d, err2);
     }
     if (lane == 0) scales[dr] = sc;
   } else {
@@ -66,8 +70,20 @@ __global__ __launch_bounds__(256) void slab_append_kernel(const float* __restric
     for (int c = lane; c < pdim; c += 64) {
       float x = 0.f;
       if (c < dim) x = src[c] / inv_den;
-      dst[c] = (_Float16)x;
+      const _Float16 h = (_Float16)x;
+      dst[c] = h;
       if (shadow && c < dim) shadow[dr * dim + c] = x;
+      const float d = x - (float)h;
+      err2 = fmaf(d, d, err2);
+    }
+  }
+  // |stored row - fp32 row|_2, maximum over the shard's rows: the row term of the exactness certificate (exact.hip).
+  // Non-negative floats order like their bit patterns; the plain read first keeps the atomics to the few rows that raise it.
+  if (row_err_max) {
+    const float err = sqrtf(wave_sum(err2)) * 1.0001f;
+    if (lane == 0) {
+      int* p = reinterpret_cast<int*>(row_err_max);
+      if (__float_as_int(err) > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, __float_as_int(err));
     }
   }
 }
@@ -177,21 +193,21 @@ int refine_f32_launch(const float* q32, int nq, int dim, const float* shadow, in
 }
 
 int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_type, void* slab,
-                       float* scales, float* shadow, int64_t row0, hipStream_t stream) {
+                       float* scales, float* shadow, int64_t row0, float* row_err_max, hipStream_t stream) {
   if (n <= 0) return 0;
   const unsigned blocks = (unsigned)((n + 3) / 4);
   if (slab_type == 1)
     hipLaunchKernelGGL((slab_append_kernel<true>), dim3(blocks), dim3(256), 0, stream, emb, n, dim,
-                       pdim, slab, scales, shadow, row0);
+                       pdim, slab, scales, shadow, row0, row_err_max);
   else
     hipLaunchKernelGGL((slab_append_kernel<false>), dim3(blocks), dim3(256), 0, stream, emb, n, dim,
-                       pdim, slab, scales, shadow, row0);
+                       pdim, slab, scales, shadow, row0, row_err_max);
   return (int)hipGetLastError();
 }
 
 int queries_to_f16_launch(const float* q, int nq, int dim, int pdim, _Float16* out,
                           hipStream_t stream) {
-  return slab_append_launch(q, nq, dim, pdim, 0, out, nullptr, nullptr, 0, stream);
+  return slab_append_launch(q, nq, dim, pdim, 0, out, nullptr, nullptr, 0, nullptr, stream);
 }
 
 int rescore_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows,

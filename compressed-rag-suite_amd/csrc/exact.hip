@@ -1,0 +1,301 @@
+// exact.hip -- the exactness certificate behind "Recall@10 = 1.0 vs the fp32 ranking", and the escalation that
+// restores it when the certificate fails (the reference stores and ranks fp32: rag/indexing.py:114-119,171-176).
+//
+// The store over-fetches k' candidates per query from the fp16 / int8 slab (crs_cosine_topk) and re-ranks them by
+// their fp32 scores against the fp32 shadow.  That result IS the fp32 top-k of ALL rows whenever no un-fetched row
+// can reach it:
+//     every un-fetched row j has   slab_score(j) <= t            (t = the k'-th slab score: the scan is exact on its
+//                                                                 own scores; + 2e-5 |t| for the last-bit difference
+//                                                                 between the scan's and the tile refine's MFMA shape)
+//     and                          |slab_score(j) - s32(j)| <= eps_q
+// so s32(j) <= t + eps_q =: bound, and the re-ranked list is exact iff its k-th fp32 score is > bound.
+// eps_q is a worst-case (Cauchy-Schwarz) bound, per query, from quantities that are MEASURED, not assumed:
+//     slab_score - s32 = <q16 - q, c^_j> + <q, c^_j - c_j>  (+ accumulation error)      c^_j = the row as the slab holds it
+//     |.| <= dq (1 + E) + |q| E + arith
+//     dq    = |q16 - q|_2 computed here from the very two query blocks the scan and the re-rank read
+//             (+ sqrt(pdim) max|q16| / 65024 for int8 slabs: the scan moves the query to 16-bit fixed point, scan_i8.hip)
+//     E     = max over the shard's rows of |c^_j - c_j|_2, tracked by slab_append (convert.hip) in a device scalar
+//     arith = (1.5 pdim + 8) 2^-23: pdim exact products summed in fp32 in any order with truncation (<= pdim 2^-23
+//             sum |a_i b_i| <= pdim 2^-23) plus the fp32 FMA chain of the re-rank (<= dim 2^-24 + the butterfly)
+// Uncertified queries (status 1) are escalated INSIDE the same stream with no host round trip: collect_above sweeps
+// the slab once more for them and lists every row whose slab score is >= (k-th fp32 score so far) - eps_q -- a row of
+// the true fp32 top-k cannot score lower -- and refine_list re-ranks that list in fp32.  Both kernels return at once
+// when every query of the batch is certified, so they sit in the hipGraph of a batch at the price of two empty launches.
+// A list longer than `cap` (more near-identical rows than that) sets status 2: the caller repeats with a larger cap.
+
+#include "scan.h"
+
+namespace crs {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float kNegInfE = -__builtin_huge_valf();
+
+__device__ __forceinline__ float wsum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ float wmax(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  return x;
+}
+
+// fp32 score of one candidate row, the arithmetic of crs_refine_f32 (convert.hip): lane-strided FMA chain + butterfly
+__device__ __forceinline__ float dot_f32(const float* __restrict__ a, const float* __restrict__ b, int dim, int lane) {
+  float acc = 0.f;
+  for (int e = lane; e < dim; e += 64) acc = fmaf(a[e], b[e], acc);
+  return wsum(acc);
+}
+
+// ---- certificate -----------------------------------------------------------------------------------------------
+// One 256-thread workgroup per query.  ws_thr / ws_cnt: the escalation workspace's per-query threshold and counter.
+__global__ __launch_bounds__(256) void refine_cert_kernel(const float* __restrict__ q32, const _Float16* __restrict__ q16, int dim,
+                                                         int pdim, int is_i8, const float* __restrict__ shadow, int64_t n_rows,
+                                                         int64_t id_base, const int64_t* __restrict__ cand,
+                                                         const float* __restrict__ cand_s, int k_in, int k_out, float err_rows,
+                                                         float err_arith, float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                         int* __restrict__ status, float* __restrict__ ws_thr, int* __restrict__ ws_cnt) {
+  __shared__ float sh_s[64];
+  __shared__ int64_t sh_i[64];
+  __shared__ float red[4][3];
+  __shared__ float kth_s;
+  const int qi = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* a = q32 + (size_t)qi * dim;
+  const _Float16* a16 = q16 + (size_t)qi * pdim;
+  // |q16 - q|^2, |q|^2, max |q16| over the padded row (elements past dim: q = 0)
+  float d2 = 0.f, n2 = 0.f, am = 0.f;
+  for (int e = t; e < pdim; e += 256) {
+    const float x = e < dim ? a[e] : 0.f, h = (float)a16[e];
+    d2 = fmaf(h - x, h - x, d2);
+    n2 = fmaf(x, x, n2);
+    am = fmaxf(am, fabsf(h));
+  }
+  d2 = wsum(d2); n2 = wsum(n2); am = wmax(am);
+  if (lane == 0) { red[wave][0] = d2; red[wave][1] = n2; red[wave][2] = am; }
+  for (int c = wave; c < k_in; c += 4) {
+    const int64_t id = cand[(size_t)qi * k_in + c];
+    const int64_t row = id - id_base;
+    const bool ok = id >= 0 && row >= 0 && row < n_rows;
+    const float acc = ok ? dot_f32(a, shadow + (size_t)row * dim, dim, lane) : 0.f;
+    if (lane == 0) { sh_s[c] = ok ? acc : kNegInfE; sh_i[c] = ok ? id : (int64_t)-1; }
+  }
+  if (t == 0) kth_s = kNegInfE;
+  __syncthreads();
+  if (t < k_out) { out_s[(size_t)qi * k_out + t] = kNegInfE; out_i[(size_t)qi * k_out + t] = -1; }
+  __syncthreads();
+  if (t < k_in) {
+    const float s = sh_s[t];
+    const int64_t id = sh_i[t];
+    if (id >= 0) {
+      int rank = 0;
+      for (int j = 0; j < k_in; ++j) {
+        const float sj = sh_s[j];
+        const int64_t ij = sh_i[j];
+        rank += (ij >= 0 && (sj > s || (sj == s && (ij < id || (ij == id && j < t))))) ? 1 : 0;
+      }
+      if (rank < k_out) { out_s[(size_t)qi * k_out + rank] = s; out_i[(size_t)qi * k_out + rank] = id; }
+      if (rank == k_out - 1) kth_s = s;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    const float dd = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    const float nn = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    const float mx = fmaxf(fmaxf(red[0][2], red[1][2]), fmaxf(red[2][2], red[3][2]));
+    float dq = sqrtf(dd) * 1.0001f;
+    if (is_i8) dq += sqrtf((float)pdim) * mx * (1.0001f / 65024.0f);
+    const float eps = dq * (1.0f + err_rows) * 1.0001f + sqrtf(nn) * err_rows * 1.0002f + err_arith;
+    // t = the k'-th slab score; fewer than k' valid candidates = every row of the shard was fetched
+    int valid = 0;
+    float tmin = __builtin_huge_valf();
+    for (int c = 0; c < k_in; ++c) {   // (a candidate id outside this shard counts as fetched-but-unusable: never certifies)
+      if (cand[(size_t)qi * k_in + c] >= 0) { ++valid; tmin = fminf(tmin, cand_s[(size_t)qi * k_in + c]); }
+    }
+    const float kth = kth_s;
+    int st = 0;
+    if (valid == k_in && (int64_t)k_in < n_rows) {
+      const float bound = tmin + eps + 2e-5f * fabsf(tmin);
+      st = (kth > bound) ? 0 : 1;        // kth == -inf (fewer than k_out candidates, all rows fetched) cannot get here
+    }
+    status[qi] = st;
+    ws_thr[qi] = kth - eps;
+    ws_cnt[qi] = 0;
+  }
+}
+
+// ---- escalation, stage 1: list every row whose slab score reaches the query's threshold ----------------------------
+// Plain fp16 MFMA sweep with fragment-shaped global loads (a rare path: no LDS staging, no selection state).
+// KS = pdim / 128.  A = 16 slab rows, B = 16 uncertified queries (resident in VGPRs for the sweep), D[row][query].
+template <int KS, bool I8>
+__global__ __launch_bounds__(256) void collect_above_kernel(const _Float16* __restrict__ q16, int nq, const void* __restrict__ slab_,
+                                                           const float* __restrict__ scales, int n_rows, int64_t id_base,
+                                                           const int* __restrict__ status, const float* __restrict__ thr,
+                                                           int cap, int* __restrict__ counts, int64_t* __restrict__ lists) {
+  constexpr int D = KS * 128, kSteps = D / 32;
+  __shared__ int need[1024];
+  __shared__ int n_need;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, kq = lane >> 4;
+  if (t == 0) n_need = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < nq; q0 += 1024) {          // uncertified queries of this chunk of the batch, in any order
+    if (q0) { __syncthreads(); if (t == 0) n_need = 0; __syncthreads(); }
+    for (int q = q0 + t; q < nq && q < q0 + 1024; q += 256)
+      if (status[q] == 1) need[atomicAdd(&n_need, 1)] = q;
+    __syncthreads();
+    const int nn = n_need;
+    for (int g = 0; g < nn; g += 16) {
+      const int myq = (g + lr < nn) ? need[g + lr] : -1;
+      f16x8 qf[kSteps];
+      const _Float16* qrow = q16 + (size_t)(myq < 0 ? 0 : myq) * D + kq * 8;
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) qf[s] = *reinterpret_cast<const f16x8*>(qrow + s * 32);
+      const float th = myq < 0 ? __builtin_huge_valf() : thr[myq];
+      const int n_tiles = (n_rows + 15) / 16;
+      for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + lr;
+        const int crow = row < n_rows ? row : n_rows - 1;
+        f16x8 af[kSteps];
+        if (I8) {
+          const int8_t* arow = reinterpret_cast<const int8_t*>(slab_) + (size_t)crow * D + kq * 8;
+#pragma unroll
+          for (int s = 0; s < kSteps; ++s) {
+            const int2 raw = *reinterpret_cast<const int2*>(arow + s * 32);
+            const int8_t* b8 = reinterpret_cast<const int8_t*>(&raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[s][e] = (_Float16)(float)b8[e];
+          }
+        } else {
+          const _Float16* arow = reinterpret_cast<const _Float16*>(slab_) + (size_t)crow * D + kq * 8;
+#pragma unroll
+          for (int s = 0; s < kSteps; ++s) af[s] = *reinterpret_cast<const f16x8*>(arow + s * 32);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], qf[s], acc, 0, 0, 0);
+        // lane (query column lr, quad kq) holds rows tile * 16 + 4 kq + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = tile * 16 + 4 * kq + i;
+          float sc = acc[i];
+          if (I8) sc *= scales[rr < n_rows ? rr : n_rows - 1];
+          if (myq >= 0 && rr < n_rows && sc >= th) {
+            const int p = atomicAdd(&counts[myq], 1);
+            if (p < cap) lists[(size_t)myq * cap + p] = (int64_t)rr + id_base;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- escalation, stage 2: fp32 re-rank of an escalated query's list ------------------------------------------------
+// One 256-thread workgroup per query; queries with status != 1 return at once.  Dynamic LDS: cap * 12 bytes.
+__global__ __launch_bounds__(256) void refine_list_kernel(const float* __restrict__ q32, int dim, const float* __restrict__ shadow,
+                                                         int64_t n_rows, int64_t id_base, int* __restrict__ status,
+                                                         const int* __restrict__ counts, const int64_t* __restrict__ lists, int cap,
+                                                         int k_out, float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int qi = blockIdx.x;
+  if (status[qi] != 1) return;
+  const int n = counts[qi];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (n > cap) {                       // more rows in the band than the list holds: the caller repeats with a larger cap
+    if (t == 0) status[qi] = 2;
+    return;
+  }
+  int64_t* li = reinterpret_cast<int64_t*>(smem);
+  float* ls = reinterpret_cast<float*>(smem + (size_t)cap * 8);
+  const float* a = q32 + (size_t)qi * dim;
+  for (int c = wave; c < n; c += 4) {
+    const int64_t id = lists[(size_t)qi * cap + c];
+    const int64_t row = id - id_base;
+    const bool ok = row >= 0 && row < n_rows;
+    const float acc = ok ? dot_f32(a, shadow + (size_t)row * dim, dim, lane) : 0.f;
+    if (lane == 0) { ls[c] = ok ? acc : kNegInfE; li[c] = ok ? id : (int64_t)-1; }
+  }
+  if (t < k_out) { out_s[(size_t)qi * k_out + t] = kNegInfE; out_i[(size_t)qi * k_out + t] = -1; }
+  __syncthreads();
+  for (int c = t; c < n; c += 256) {
+    const float s = ls[c];
+    const int64_t id = li[c];
+    if (id < 0) continue;
+    int rank = 0;
+    for (int j = 0; j < n && rank < k_out; ++j) {
+      const float sj = ls[j];
+      const int64_t ij = li[j];
+      rank += (ij >= 0 && (sj > s || (sj == s && ij < id))) ? 1 : 0;
+    }
+    if (rank < k_out) { out_s[(size_t)qi * k_out + rank] = s; out_i[(size_t)qi * k_out + rank] = id; }
+  }
+}
+
+template <int KS>
+void launch_collect(bool i8, unsigned grid, hipStream_t st, const _Float16* q16, int nq, const void* slab, const float* scales,
+                    int n_rows, int64_t id_base, const int* status, const float* thr, int cap, int* counts, int64_t* lists) {
+  if (i8)
+    hipLaunchKernelGGL((collect_above_kernel<KS, true>), dim3(grid), dim3(256), 0, st, q16, nq, slab, scales, n_rows, id_base, status,
+                       thr, cap, counts, lists);
+  else
+    hipLaunchKernelGGL((collect_above_kernel<KS, false>), dim3(grid), dim3(256), 0, st, q16, nq, slab, scales, n_rows, id_base, status,
+                       thr, cap, counts, lists);
+}
+
+}  // namespace
+
+float exact_err_arith(int dim, int pdim) { return (1.5f * (float)pdim + 8.0f) * 1.1920929e-7f; }
+
+// Worst-case |stored row - fp32 row|_2 when the store did not track it: fp16 rounds each element to 2^-11 relative
+// (2^-25 absolute below the normal range); an int8 row errs by at most scale / 2 = max|x| / 254 <= 1 / 254 per element.
+float exact_err_rows_bound(int dim, int slab_type) {
+  if (slab_type == 1) return sqrtf((float)dim) / 254.0f * 1.0001f;
+  return 4.8828125e-4f * 1.0001f + sqrtf((float)dim) * 2.98023224e-8f;
+}
+
+int refine_cert_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const float* shadow,
+                       int64_t n_rows, int64_t id_base, const int64_t* cand, const float* cand_s, int k_in, int k_out,
+                       float err_rows, float* out_s, int64_t* out_i, int* status, float* ws_thr, int* ws_cnt, hipStream_t stream) {
+  if (nq <= 0) return 0;
+  hipLaunchKernelGGL(refine_cert_kernel, dim3(nq), dim3(256), 0, stream, q32, q16, dim, pdim, slab_type == 1 ? 1 : 0, shadow, n_rows,
+                     id_base, cand, cand_s, k_in, k_out, err_rows, exact_err_arith(dim, pdim), out_s, out_i, status, ws_thr, ws_cnt);
+  return (int)hipGetLastError();
+}
+
+int escalate_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const void* slab,
+                    const float* scales, const float* shadow, int64_t n_rows, int64_t id_base, int k_out, float* out_s,
+                    int64_t* out_i, int* status, const float* ws_thr, int* ws_cnt, int64_t* ws_lists, int cap, int cus,
+                    hipStream_t stream) {
+  if (nq <= 0) return 0;
+  const bool i8 = slab_type == 1;
+  const int64_t tiles = (n_rows + 15) / 16;
+  int64_t g = (tiles + 3) / 4;
+  const int64_t gmax = (int64_t)(cus > 0 ? cus : 256) * 4;
+  const unsigned grid = (unsigned)(g < gmax ? (g < 1 ? 1 : g) : gmax);
+  switch (pdim / 128) {
+    case 1: launch_collect<1>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 2: launch_collect<2>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 3: launch_collect<3>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 4: launch_collect<4>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 5: launch_collect<5>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 6: launch_collect<6>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 7: launch_collect<7>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 8: launch_collect<8>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    default: return -1;
+  }
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  if ((size_t)cap * 12 > 48 * 1024) {     // beyond the default dynamic-LDS limit (up to the CU's 160 KiB: cap <= 13312)
+    const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(refine_list_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, cap * 12);
+    if (ae != hipSuccess) return (int)ae;
+  }
+  hipLaunchKernelGGL(refine_list_kernel, dim3(nq), dim3(256), (size_t)cap * 12, stream, q32, dim, shadow, n_rows, id_base, status,
+                     ws_cnt, ws_lists, cap, k_out, out_s, out_i);
+  return (int)hipGetLastError();
+}
+
+}  // namespace crs

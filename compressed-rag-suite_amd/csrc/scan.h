@@ -70,9 +70,20 @@ int merge_launch_wire(const void* wire, size_t block_bytes, size_t scores_off, i
 int refine_f32_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows, int64_t id_base,
                       const int64_t* cand, int k_in, int k_out, float* out_s, int64_t* out_i, hipStream_t stream);
 int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_type, void* slab,
-                       float* scales, float* shadow, int64_t row0, hipStream_t stream);
+                       float* scales, float* shadow, int64_t row0, float* row_err_max, hipStream_t stream);
 int queries_to_f16_launch(const float* q, int nq, int dim, int pdim, _Float16* out, hipStream_t stream);
 int rescore_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows,
                    int64_t id_base, int k, float* scores, int64_t* ids, hipStream_t stream);
+
+// exact.hip: exactness certificate of the over-fetch re-rank + in-stream escalation of uncertified queries
+float exact_err_arith(int dim, int pdim);
+float exact_err_rows_bound(int dim, int slab_type);
+int refine_cert_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const float* shadow,
+                       int64_t n_rows, int64_t id_base, const int64_t* cand, const float* cand_s, int k_in, int k_out,
+                       float err_rows, float* out_s, int64_t* out_i, int* status, float* ws_thr, int* ws_cnt, hipStream_t stream);
+int escalate_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const void* slab,
+                    const float* scales, const float* shadow, int64_t n_rows, int64_t id_base, int k_out, float* out_s,
+                    int64_t* out_i, int* status, const float* ws_thr, int* ws_cnt, int64_t* ws_lists, int cap, int cus,
+                    hipStream_t stream);
 
 }  // namespace crs

@@ -7,6 +7,8 @@
 //   crs::queries_to_f16    query side of the same conversion                  (reference rag/indexing.py:156-168)
 //   crs::cosine_topk       replaces collection.query(query_embeddings, n)     (reference rag/indexing.py:171-176)
 //   crs::refine_f32        over-fetch re-rank against the fp32 shadow         
+//   crs::refine_f32_cert / crs::escalate_exact   the same with a per-query exactness proof, and the in-stream
+//                          escalation of unproven queries (identical ids to an fp32 store: rag/indexing.py:171-176)
 //   crs::merge_topk / crs::merge_topk_wire   cross-shard merge                (new vs the reference)
 // Tensors are torch-owned; every op launches on the CURRENT HIP stream of the tensors' device, so the ops
 // compose with torch streams and hipGraph capture.  Errors of the C ABI surface as RuntimeError (TORCH_CHECK)
@@ -38,6 +40,15 @@ void want(const Tensor& t, at::ScalarType ty, const char* name) {
   TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
 }
 const void* opt_ptr(const c10::optional<Tensor>& t) { return (t.has_value() && t->defined()) ? t->data_ptr() : nullptr; }
+bool has(const c10::optional<Tensor>& t) { return t.has_value() && t->defined(); }
+
+// every tensor of a call must live on the device whose stream and guard the op uses: with a one-process multi-device
+// store a mismatched tensor would otherwise be a GPU memory fault (or a silent wrong-device read), not an exception
+void same_device(const Tensor& ref, std::initializer_list<const Tensor*> ts, const char* op) {
+  for (const Tensor* t : ts)
+    if (t && t->defined()) TORCH_CHECK(t->device() == ref.device(), op, ": all tensors must be on ", ref.device(), ", got one on ", t->device());
+}
+const Tensor* opt_t(const c10::optional<Tensor>& t) { return has(t) ? &*t : nullptr; }
 
 int slab_type_of(const Tensor& slab) {
   TORCH_CHECK(slab.scalar_type() == at::kHalf || slab.scalar_type() == at::kChar, "slab must be fp16 or int8");
@@ -45,8 +56,11 @@ int slab_type_of(const Tensor& slab) {
 }
 
 // ---- index build ---------------------------------------------------------------------------------------------
-void slab_append(const Tensor& emb, Tensor slab, c10::optional<Tensor> scales, c10::optional<Tensor> shadow, int64_t row0) {
+void slab_append(const Tensor& emb, Tensor slab, c10::optional<Tensor> scales, c10::optional<Tensor> shadow, int64_t row0,
+                 c10::optional<Tensor> row_err) {
   want(emb, at::kFloat, "emb");
+  same_device(emb, {&slab, opt_t(scales), opt_t(shadow), opt_t(row_err)}, "crs::slab_append");
+  if (has(row_err)) { want(*row_err, at::kFloat, "row_err"); TORCH_CHECK(row_err->numel() >= 1, "row_err must hold one fp32"); }
   TORCH_CHECK(emb.dim() == 2 && slab.dim() == 2 && slab.is_cuda() && slab.is_contiguous(), "emb [n, dim], slab [cap, pdim]");
   const int st = slab_type_of(slab);
   const int64_t n = emb.size(0);
@@ -64,12 +78,13 @@ void slab_append(const Tensor& emb, Tensor slab, c10::optional<Tensor> scales, c
   }
   c10::hip::HIPGuardMasqueradingAsCUDA g(emb.device());
   ok(crs_slab_append_f32(emb.data_ptr<float>(), n, dim, st, slab.data_ptr(), (float*)opt_ptr(scales), (float*)opt_ptr(shadow), row0,
-                         cur_stream(emb)), "crs::slab_append");
+                         (float*)opt_ptr(row_err), cur_stream(emb)), "crs::slab_append");
 }
 
 void queries_to_f16(const Tensor& q32, Tensor out16, int64_t slab_type) {
   want(q32, at::kFloat, "q32");
   want(out16, at::kHalf, "out16");
+  same_device(q32, {&out16}, "crs::queries_to_f16");
   TORCH_CHECK(q32.dim() == 2 && out16.dim() == 2 && out16.size(0) == q32.size(0) &&
                   out16.size(1) == crs_row_elems((int)q32.size(1), (int)slab_type), "out16 must be [nq, crs_row_elems(dim, slab_type)]");
   c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
@@ -92,9 +107,11 @@ void cosine_topk_out(const Tensor& q16, const Tensor& slab, c10::optional<Tensor
   TORCH_CHECK(out_scores.numel() == nq * k && out_ids.numel() == nq * k, "outputs must hold [nq, k]");
   TORCH_CHECK(workspace.is_cuda() && workspace.is_contiguous(), "workspace must be a contiguous device tensor");
   if (st == CRS_SLAB_I8) {
-    TORCH_CHECK(scales.has_value(), "int8 slab needs scales");
+    TORCH_CHECK(has(scales), "int8 slab needs scales");
     want(*scales, at::kFloat, "scales");
+    TORCH_CHECK(scales->numel() >= n_rows, "scales shorter than n_rows");
   }
+  same_device(q16, {&slab, opt_t(scales), &workspace, &out_scores, &out_ids}, "crs::cosine_topk");
   c10::hip::HIPGuardMasqueradingAsCUDA g(q16.device());
   ok(crs_cosine_topk(q16.data_ptr(), (int)nq, (int)dim, st, slab.data_ptr(), (const float*)opt_ptr(scales), n_rows, (int)k, id_base,
                      workspace.data_ptr(), (size_t)workspace.nbytes(), out_scores.data_ptr<float>(), out_ids.data_ptr<int64_t>(),
@@ -124,10 +141,70 @@ void refine_f32_out(const Tensor& q32, const Tensor& shadow, int64_t n_rows, int
   TORCH_CHECK(q32.dim() == 2 && shadow.dim() == 2 && cand_ids.dim() == 2 && shadow.size(1) == q32.size(1) &&
                   cand_ids.size(0) == q32.size(0) && n_rows <= shadow.size(0), "q32 [nq, dim], shadow [>= n_rows, dim], cand_ids [nq, k_in]");
   TORCH_CHECK(out_scores.numel() == q32.size(0) * k_out && out_ids.numel() == q32.size(0) * k_out, "outputs must hold [nq, k_out]");
+  TORCH_CHECK(cand_ids.size(1) >= k_out, "cand_ids holds fewer than k_out candidates per query");
+  same_device(q32, {&shadow, &cand_ids, &out_scores, &out_ids}, "crs::refine_f32");
   c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
   ok(crs_refine_f32(q32.data_ptr<float>(), (int)q32.size(0), (int)q32.size(1), shadow.data_ptr<float>(), n_rows, id_base,
                     cand_ids.data_ptr<int64_t>(), (int)cand_ids.size(1), (int)k_out, out_scores.data_ptr<float>(),
                     out_ids.data_ptr<int64_t>(), cur_stream(q32)), "crs::refine_f32");
+}
+
+// ---- exactness certificate + escalation (include/crs_hip.h, csrc/exact.hip) --------------------------------------------------
+void refine_f32_cert_out(const Tensor& q32, const Tensor& q16, const Tensor& shadow, int64_t n_rows, int64_t id_base,
+                         const Tensor& cand_ids, const Tensor& cand_scores, int64_t k_out, double row_err_max, int64_t slab_type,
+                         Tensor out_scores, Tensor out_ids, Tensor status, Tensor exact_ws, int64_t cap) {
+  want(q32, at::kFloat, "q32");
+  want(q16, at::kHalf, "q16");
+  want(shadow, at::kFloat, "shadow");
+  want(cand_ids, at::kLong, "cand_ids");
+  want(cand_scores, at::kFloat, "cand_scores");
+  want(out_scores, at::kFloat, "out_scores");
+  want(out_ids, at::kLong, "out_ids");
+  want(status, at::kInt, "status");
+  TORCH_CHECK(exact_ws.is_cuda() && exact_ws.is_contiguous(), "exact_ws must be a contiguous device tensor");
+  const int64_t nq = q32.size(0);
+  TORCH_CHECK(q32.dim() == 2 && q16.dim() == 2 && shadow.dim() == 2 && cand_ids.dim() == 2 && shadow.size(1) == q32.size(1) &&
+                  cand_ids.size(0) == nq && cand_scores.sizes() == cand_ids.sizes() && n_rows <= shadow.size(0) && q16.size(0) == nq &&
+                  q16.size(1) == crs_row_elems((int)q32.size(1), (int)slab_type),
+              "q32 [nq, dim], q16 [nq, crs_row_elems], shadow [>= n_rows, dim], cand_ids / cand_scores [nq, k_in]");
+  TORCH_CHECK(out_scores.numel() == nq * k_out && out_ids.numel() == nq * k_out && status.numel() == nq, "outputs must hold [nq, k_out], status [nq]");
+  same_device(q32, {&q16, &shadow, &cand_ids, &cand_scores, &out_scores, &out_ids, &status, &exact_ws}, "crs::refine_f32_cert");
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
+  ok(crs_refine_f32_cert(q32.data_ptr<float>(), q16.data_ptr(), (int)nq, (int)q32.size(1), (int)slab_type, shadow.data_ptr<float>(), n_rows,
+                         id_base, cand_ids.data_ptr<int64_t>(), cand_scores.data_ptr<float>(), (int)cand_ids.size(1), (int)k_out,
+                         (float)row_err_max, out_scores.data_ptr<float>(), out_ids.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
+                         exact_ws.data_ptr(), (size_t)exact_ws.nbytes(), (int)cap, cur_stream(q32)), "crs::refine_f32_cert");
+}
+
+void escalate_exact(const Tensor& q32, const Tensor& q16, const Tensor& slab, c10::optional<Tensor> scales, const Tensor& shadow,
+                    int64_t n_rows, int64_t id_base, int64_t k_out, Tensor out_scores, Tensor out_ids, Tensor status, Tensor exact_ws,
+                    int64_t cap) {
+  want(q32, at::kFloat, "q32");
+  want(q16, at::kHalf, "q16");
+  want(shadow, at::kFloat, "shadow");
+  want(out_scores, at::kFloat, "out_scores");
+  want(out_ids, at::kLong, "out_ids");
+  want(status, at::kInt, "status");
+  TORCH_CHECK(slab.is_cuda() && slab.is_contiguous() && slab.dim() == 2, "slab [rows, pdim]");
+  TORCH_CHECK(exact_ws.is_cuda() && exact_ws.is_contiguous(), "exact_ws must be a contiguous device tensor");
+  const int st = slab_type_of(slab);
+  const int64_t nq = q32.size(0);
+  const int pdim = crs_row_elems((int)q32.size(1), st);
+  TORCH_CHECK(q32.dim() == 2 && q16.dim() == 2 && q16.size(0) == nq && q16.size(1) == pdim && slab.size(1) == pdim && shadow.dim() == 2 &&
+                  shadow.size(1) == q32.size(1) && n_rows >= 1 && n_rows <= slab.size(0) && n_rows <= shadow.size(0),
+              "q32 [nq, dim], q16 [nq, pdim], slab [>= n_rows, pdim], shadow [>= n_rows, dim]");
+  TORCH_CHECK(out_scores.numel() == nq * k_out && out_ids.numel() == nq * k_out && status.numel() == nq, "outputs must hold [nq, k_out], status [nq]");
+  if (st == CRS_SLAB_I8) {
+    TORCH_CHECK(has(scales), "int8 slab needs scales");
+    want(*scales, at::kFloat, "scales");
+    TORCH_CHECK(scales->numel() >= n_rows, "scales shorter than n_rows");
+  }
+  same_device(q32, {&q16, &slab, opt_t(scales), &shadow, &out_scores, &out_ids, &status, &exact_ws}, "crs::escalate_exact");
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
+  ok(crs_escalate_exact(q32.data_ptr<float>(), q16.data_ptr(), (int)nq, (int)q32.size(1), st, slab.data_ptr(), (const float*)opt_ptr(scales),
+                        shadow.data_ptr<float>(), n_rows, id_base, (int)k_out, out_scores.data_ptr<float>(), out_ids.data_ptr<int64_t>(),
+                        status.data_ptr<int32_t>(), exact_ws.data_ptr(), (size_t)exact_ws.nbytes(), (int)cap, cur_stream(q32)),
+     "crs::escalate_exact");
 }
 
 std::tuple<Tensor, Tensor> refine_f32(const Tensor& q32, const Tensor& shadow, int64_t n_rows, int64_t id_base, const Tensor& cand_ids,
@@ -146,6 +223,7 @@ void merge_topk_out(const Tensor& scores, const Tensor& ids, int64_t k_out, Tens
   want(out_ids, at::kLong, "out_ids");
   TORCH_CHECK(scores.dim() == 3 && ids.sizes() == scores.sizes(), "scores / ids must be [nlists, nq, k_in]");
   TORCH_CHECK(out_scores.numel() == scores.size(1) * k_out && out_ids.numel() == scores.size(1) * k_out, "outputs must hold [nq, k_out]");
+  same_device(scores, {&ids, &out_scores, &out_ids}, "crs::merge_topk");
   c10::hip::HIPGuardMasqueradingAsCUDA g(scores.device());
   ok(crs_merge_topk(scores.data_ptr<float>(), ids.data_ptr<int64_t>(), (int)scores.size(0), (int)scores.size(1), (int)scores.size(2),
                     (int)k_out, out_scores.data_ptr<float>(), out_ids.data_ptr<int64_t>(), cur_stream(scores)), "crs::merge_topk");
@@ -166,6 +244,7 @@ void merge_topk_wire_out(const Tensor& wire, int64_t nlists, int64_t nq, int64_t
   want(out_scores, at::kFloat, "out_scores");
   want(out_ids, at::kLong, "out_ids");
   TORCH_CHECK(out_scores.numel() == nq * k_out && out_ids.numel() == nq * k_out, "outputs must hold [nq, k_out]");
+  same_device(wire, {&out_scores, &out_ids}, "crs::merge_topk_wire");
   c10::hip::HIPGuardMasqueradingAsCUDA g(wire.device());
   ok(crs_merge_topk_wire(wire.data_ptr(), (int)nlists, (int)nq, (int)k_in, (int)k_out, out_scores.data_ptr<float>(),
                          out_ids.data_ptr<int64_t>(), cur_stream(wire)), "crs::merge_topk_wire");
@@ -184,7 +263,8 @@ void encoder_forward(const Tensor& ids, const Tensor& lens, at::TensorList weigh
                      (float)ln_eps, (int32_t)desc[6]};
   TORCH_CHECK((int64_t)weights.size() == 5 + 12 * (int64_t)d.layers, "weights must hold 5 + 12 * layers tensors");
   TORCH_CHECK(ids.dim() == 2 && lens.numel() == ids.size(0) && out.numel() == ids.size(0) * d.hidden, "ids [B, S], lens [B], out [B, H]");
-  for (const Tensor& t : weights) TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "weights must be contiguous device tensors");
+  for (const Tensor& t : weights) TORCH_CHECK(t.is_cuda() && t.is_contiguous() && t.device() == ids.device(), "weights must be contiguous tensors on the device of ids");
+  same_device(ids, {&lens, &workspace, &out, opt_t(q16_out), opt_t(hidden_out)}, "crs::encoder_forward");
   std::vector<crs_encoder_layer> layers((size_t)d.layers);
   for (int l = 0; l < d.layers; ++l) {
     const Tensor* w = &weights[5 + 12 * l];
@@ -218,7 +298,7 @@ void encoder_forward(const Tensor& ids, const Tensor& lens, at::TensorList weigh
 }  // namespace
 
 TORCH_LIBRARY(crs, m) {
-  m.def("slab_append(Tensor emb, Tensor(a!) slab, Tensor(b!)? scales, Tensor(c!)? shadow, int row0) -> ()");
+  m.def("slab_append(Tensor emb, Tensor(a!) slab, Tensor(b!)? scales, Tensor(c!)? shadow, int row0, Tensor(d!)? row_err) -> ()");
   m.def("queries_to_f16(Tensor q32, Tensor(a!) out16, int slab_type) -> ()");
   m.def("cosine_topk(Tensor q16, Tensor slab, Tensor? scales, int n_rows, int dim, int k, int id_base) -> (Tensor, Tensor)");
   m.def("cosine_topk_out(Tensor q16, Tensor slab, Tensor? scales, int n_rows, int dim, int k, int id_base, Tensor(a!) workspace, "
@@ -226,6 +306,10 @@ TORCH_LIBRARY(crs, m) {
   m.def("refine_f32(Tensor q32, Tensor shadow, int n_rows, int id_base, Tensor cand_ids, int k_out) -> (Tensor, Tensor)");
   m.def("refine_f32_out(Tensor q32, Tensor shadow, int n_rows, int id_base, Tensor cand_ids, int k_out, Tensor(a!) out_scores, "
         "Tensor(b!) out_ids) -> ()");
+  m.def("refine_f32_cert_out(Tensor q32, Tensor q16, Tensor shadow, int n_rows, int id_base, Tensor cand_ids, Tensor cand_scores, int k_out, "
+        "float row_err_max, int slab_type, Tensor(a!) out_scores, Tensor(b!) out_ids, Tensor(c!) status, Tensor(d!) exact_ws, int cap) -> ()");
+  m.def("escalate_exact(Tensor q32, Tensor q16, Tensor slab, Tensor? scales, Tensor shadow, int n_rows, int id_base, int k_out, "
+        "Tensor(a!) out_scores, Tensor(b!) out_ids, Tensor(c!) status, Tensor(d!) exact_ws, int cap) -> ()");
   m.def("merge_topk(Tensor scores, Tensor ids, int k_out) -> (Tensor, Tensor)");
   m.def("merge_topk_out(Tensor scores, Tensor ids, int k_out, Tensor(a!) out_scores, Tensor(b!) out_ids) -> ()");
   m.def("merge_topk_wire_out(Tensor wire, int nlists, int nq, int k_in, int k_out, Tensor(a!) out_scores, Tensor(b!) out_ids) -> ()");
@@ -240,6 +324,8 @@ TORCH_LIBRARY_IMPL(crs, CUDA, m) {   // the HIP backend of torch-ROCm dispatches
   m.impl("cosine_topk_out", &cosine_topk_out);
   m.impl("refine_f32", &refine_f32);
   m.impl("refine_f32_out", &refine_f32_out);
+  m.impl("refine_f32_cert_out", &refine_f32_cert_out);
+  m.impl("escalate_exact", &escalate_exact);
   m.impl("merge_topk", &merge_topk);
   m.impl("merge_topk_out", &merge_topk_out);
   m.impl("merge_topk_wire_out", &merge_topk_wire_out);

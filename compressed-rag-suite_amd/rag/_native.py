@@ -20,6 +20,8 @@ TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libcrs_torch.so")
 SLAB_F16 = 0
 SLAB_I8 = 1
 MAX_K = 64
+EXACT_MAX_CAP = 13312      # CRS_EXACT_MAX_CAP: longest per-query row list of crs_escalate_exact
+EXACT_CAP = 1024           # default list length (12 KB of LDS per query in the re-rank)
 
 # name -> (restype, argtypes); mirrors include/crs_hip.h one to one
 _SIGNATURES = {
@@ -28,7 +30,7 @@ _SIGNATURES = {
     "crs_padded_dim": (c_int, [c_int]),
     "crs_row_elems": (c_int, [c_int, c_int]),
     "crs_slab_append_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_int64, c_void_p]),
+                                    c_int64, c_void_p, c_void_p]),
     "crs_queries_to_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "crs_scan_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_size_t)]),
     "crs_cosine_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int,
@@ -39,6 +41,12 @@ _SIGNATURES = {
                                 c_void_p, c_void_p]),
     "crs_refine_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int,
                                c_void_p, c_void_p, c_void_p]),
+    "crs_exact_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "crs_exact_row_error_bound": (c_float, [c_int, c_int]),
+    "crs_refine_f32_cert": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                    c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "crs_escalate_exact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "crs_wire_bytes": (c_size_t, [c_int, c_int]),
     "crs_wire_scores_offset": (c_size_t, [c_int, c_int]),
     "crs_merge_topk_wire": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -142,12 +150,13 @@ def require_gpu():
 
 
 # ----------------------------------------------------------------------------- wrappers
-def slab_append_f32(emb, slab, row0: int, slab_type: int, scales=None, shadow=None) -> None:
-    """emb: cuda fp32 [n, dim]; slab: cuda fp16/int8 [cap, pdim]; writes rows row0..row0+n."""
+def slab_append_f32(emb, slab, row0: int, slab_type: int, scales=None, shadow=None, row_err=None) -> None:
+    """emb: cuda fp32 [n, dim]; slab: cuda fp16/int8 [cap, pdim]; writes rows row0..row0+n.
+    row_err: cuda fp32 [1] (zeroed by the owner of the slab) raised to the largest |stored row - fp32 row|_2."""
     if emb.shape[0] == 0:
         return
     with _translate():
-        ops().slab_append(emb, slab, scales, shadow, int(row0))
+        ops().slab_append(emb, slab, scales, shadow, int(row0), row_err)
 
 
 def queries_to_f16(q32, slab_type: int = SLAB_F16, out=None):
@@ -215,6 +224,42 @@ def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out
     with _translate():
         ops().refine_f32_out(q32, shadow, int(n_rows), int(id_base), cand_ids, int(k_out), out_scores, out_ids)
     return out_scores, out_ids
+
+
+def exact_workspace_bytes(nq: int, cap: int = EXACT_CAP) -> int:
+    return int(load().crs_exact_workspace_bytes(int(nq), int(cap)))
+
+
+def exact_row_error_bound(dim: int, slab_type: int) -> float:
+    """Analytic worst case of |stored row - fp32 row|_2 (used when a slab did not track it)."""
+    return float(load().crs_exact_row_error_bound(int(dim), int(slab_type)))
+
+
+def refine_f32_cert(q32, q16, shadow, n_rows: int, id_base: int, cand_ids, cand_scores, k_out: int, row_err_max: float,
+                    slab_type: int, exact_ws, cap: int = EXACT_CAP, out_scores=None, out_ids=None, status=None):
+    """crs_refine_f32 + the per-query exactness proof: returns (scores [nq, k_out], ids [nq, k_out], status int32 [nq])
+    with status 0 = the list is provably the fp32 top-k of all n_rows rows, 1 = not proven (feed escalate_exact)."""
+    import torch
+    nq = q32.shape[0]
+    if out_scores is None:
+        out_scores = torch.empty((nq, k_out), dtype=torch.float32, device=q32.device)
+    if out_ids is None:
+        out_ids = torch.empty((nq, k_out), dtype=torch.int64, device=q32.device)
+    if status is None:
+        status = torch.empty(nq, dtype=torch.int32, device=q32.device)
+    with _translate():
+        ops().refine_f32_cert_out(q32, q16, shadow, int(n_rows), int(id_base), cand_ids, cand_scores, int(k_out),
+                                  float(row_err_max), int(slab_type), out_scores, out_ids, status, exact_ws, int(cap))
+    return out_scores, out_ids, status
+
+
+def escalate_exact(q32, q16, slab, shadow, n_rows: int, id_base: int, k_out: int, out_scores, out_ids, status, exact_ws,
+                   cap: int = EXACT_CAP, scales=None) -> None:
+    """Make every status-1 query of a refine_f32_cert result exact, in place, on the current stream (no host sync;
+    returns at once on the device when nothing is to do).  status 2 afterwards = list longer than cap."""
+    with _translate():
+        ops().escalate_exact(q32, q16, slab, scales, shadow, int(n_rows), int(id_base), int(k_out), out_scores, out_ids,
+                             status, exact_ws, int(cap))
 
 
 class WireBlock:

@@ -10,8 +10,18 @@ ids and metadata stay on the host, indexed by row.
 New, additive surface (all keys absent from the reference config.json default so that it works unmodified):
   ``search_batch``            many queries per launch
   ``index_dtype``             'fp16' (default) | 'int8' (per-row scale)
-  ``refine_fp32``             keep an fp32 shadow of the rows, over-fetch ``refine_overfetch`` (16) candidates and re-rank
-                              them in fp32 (crs::refine_f32): the ranking an fp32 store such as the reference's returns
+  ``refine_fp32``             (default ON) keep an fp32 shadow of the rows (4 x dim bytes per row beside the fp16 / int8
+                              slab), over-fetch ``refine_overfetch`` (32) candidates and re-rank them in fp32: the ranking an
+                              fp32 store such as the reference's returns (rag/indexing.py:114-119,171-176).  False = the
+                              plain fp16 / int8 ranking, no shadow
+  ``refine_exact``            'auto' (default) | True | False: every re-ranked list carries a per-query PROOF that it is the
+                              fp32 top-k of all rows (crs::refine_f32_cert: k-th fp32 score > k'-th slab score + a measured
+                              error bound); unproven queries (near-ties deeper than the over-fetch, e.g. near-duplicate
+                              chunks) are escalated on the device (crs::escalate_exact: one more sweep lists every row that
+                              can still rank, fp32 re-rank of the list).  'auto' escalates on fp16 slabs; on int8 slabs the
+                              bound (~1e-2 for 768-d rows) is wider than typical score gaps, so the certificate rarely
+                              holds at k' = 32 and escalating would cost a second sweep for most batches: int8 stays
+                              EMPIRICAL (re-rank only) unless refine_exact=True.  ``last_exactness`` reports the counts
   ``num_gpus`` / ``devices``  ONE process driving N devices: contiguous row shards, per-device scans, partial lists
                               copied to the first device and merged there -- RAGPipeline stays one object
   ``sharded``                 SPMD (one process per GPU, torch.distributed): each rank keeps a row shard; ONE RCCL
@@ -44,7 +54,13 @@ class _Shard:
     """The rows one device holds: slab (+ scales, + fp32 shadow) and, per local row, the global sidecar row."""
 
     def __init__(self, index_dtype: str, refine_fp32: bool, device):
+        import torch
         self.index_dtype, self.refine_fp32, self.device = index_dtype, refine_fp32, device
+        # largest |stored row - fp32 row|_2 of this shard, raised by every crs::slab_append: the row term of the
+        # exactness certificate (csrc/exact.hip).  Lives on the device; read back lazily (row_err_max()).
+        self.row_err = torch.zeros(1, dtype=torch.float32, device=device)
+        self._row_err_host = None
+        self._exact_ws = {}            # (nq, cap) -> uint8 workspace of the certificate / escalation
         self.dim: Optional[int] = None
         self.pdim: Optional[int] = None
         self.n = 0
@@ -92,11 +108,29 @@ class _Shard:
         if m == 0:
             return
         with torch.cuda.device(self.device):
-            nat.slab_append_f32(emb, self.slab, self.n, self.slab_type, scales=self.scales, shadow=self.shadow)
+            nat.slab_append_f32(emb, self.slab, self.n, self.slab_type, scales=self.scales, shadow=self.shadow,
+                                row_err=self.row_err)
+            self._row_err_host = None
             self.rows_global[self.n: self.n + m] = torch.arange(first_global_row, first_global_row + m, device=self.device)
         if first_global_row != self.n:
             self.identity = False
         self.n += m
+
+    def row_err_max(self) -> float:
+        """The tracked row error as a host float (one 4-byte D2H after an append, cached until the next one)."""
+        if self._row_err_host is None:
+            self._row_err_host = float(self.row_err.item())
+        return self._row_err_host
+
+    def exact_workspace(self, nq: int, cap: int):
+        import torch
+        key = (nq, cap)
+        ws = self._exact_ws.get(key)
+        if ws is None:
+            if len(self._exact_ws) > 8:
+                self._exact_ws.clear()
+            ws = self._exact_ws[key] = torch.empty(nat.exact_workspace_bytes(nq, cap), dtype=torch.uint8, device=self.device)
+        return ws
 
     def workspace(self, nq: int, k: int, n_rows: int):
         import torch
@@ -167,8 +201,17 @@ class VectorStore:
         self.index_dtype = config.get('index_dtype', 'fp16')
         if self.index_dtype not in ('fp16', 'int8'):
             raise ValueError(f"index_dtype must be 'fp16' or 'int8', got {self.index_dtype!r}")
-        self.refine_fp32 = bool(config.get('refine_fp32', False))
-        self.refine_overfetch = int(config.get('refine_overfetch', 16))
+        refine = config.get('refine_fp32', 'auto')
+        self.refine_fp32 = True if refine == 'auto' else bool(refine)
+        self.refine_overfetch = int(config.get('refine_overfetch', 32))
+        exact = config.get('refine_exact', 'auto')
+        if exact not in ('auto', True, False):
+            raise ValueError(f"refine_exact must be 'auto', True or False, got {exact!r}")
+        self.refine_exact = exact
+        self.exact_cap = int(config.get('exact_cap', nat.EXACT_CAP))
+        # certificate outcome of the most recent search: queries proven exact by the over-fetch alone / escalated to
+        # exactness on the device / left unproven (escalation off, or a band of more than EXACT_MAX_CAP near-identical rows)
+        self.last_exactness = {"queries": 0, "certified": 0, "escalated": 0, "unproven": 0}
         self.sharded = bool(config.get('sharded', False))
         self._device = config.get('device', None)
         self._devices_cfg = config.get('devices', None)
@@ -251,6 +294,9 @@ class VectorStore:
                 sh.rows_global[: hi - lo] = torch.arange(lo, hi, device=sh.device)
             sh.n = hi - lo
             sh.identity = (lo == 0)
+            # the certificate's row term: the persisted maximum, or the analytic worst case for files written before it existed
+            sh.row_err.fill_(float(z["row_err_max"]) if "row_err_max" in z.files
+                             else nat.exact_row_error_bound(dim, nat.SLAB_I8 if dtype == "int8" else nat.SLAB_F16))
         col.ids, col.documents, col.metadatas = side["ids"], side["documents"], side["metadatas"]
         self.collection = col
         logger.info(f"Loaded existing collection: {self.collection_name} ({col.count()} rows)")
@@ -269,7 +315,8 @@ class VectorStore:
         def gather(name):
             return torch.cat([getattr(s, name)[: s.n].cpu() for s in col.shards]).numpy()[order]
 
-        arrays = {"slab": gather("slab"), "n": np.int64(col.n), "dim": np.int64(col.dim), "index_dtype": np.str_(col.index_dtype)}
+        arrays = {"slab": gather("slab"), "n": np.int64(col.n), "dim": np.int64(col.dim), "index_dtype": np.str_(col.index_dtype),
+                  "row_err_max": np.float32(max(sh.row_err_max() for sh in col.shards))}
         if col.slab_type == nat.SLAB_I8:
             arrays["scales"] = gather("scales")
         if col.refine_fp32:
@@ -335,8 +382,15 @@ class VectorStore:
             raise
 
     # -- search --------------------------------------------------------------------------------
-    def _search_shard(self, sh: _Shard, q32, top_k: int, allowed_t):
-        """q32: fp32 [nq, dim] on the shard's device -> (scores [nq, top_k], GLOBAL sidecar rows [nq, top_k]) there."""
+    def _escalates(self, sh: _Shard) -> bool:
+        """refine_exact 'auto': fp16 slabs escalate unproven queries, int8 slabs stay empirical (module docstring)."""
+        if self.refine_exact == 'auto':
+            return sh.slab_type == nat.SLAB_F16
+        return bool(self.refine_exact)
+
+    def _search_shard(self, sh: _Shard, q32, top_k: int, allowed_t, cap: Optional[int] = None):
+        """q32: fp32 [nq, dim] on the shard's device -> (scores [nq, top_k], GLOBAL sidecar rows [nq, top_k], certificate
+        status int32 [nq] or None) there.  Nothing here waits for the device."""
         import torch
         nq = q32.shape[0]
         slab, scales, shadow, n = sh.slab, sh.scales, sh.shadow, sh.n
@@ -349,8 +403,9 @@ class VectorStore:
             row_map, n = sh.rows_global[local], int(local.numel())
         if n == 0:
             return (torch.full((nq, top_k), float("-inf"), dtype=torch.float32, device=sh.device),
-                    torch.full((nq, top_k), -1, dtype=torch.int64, device=sh.device))
+                    torch.full((nq, top_k), -1, dtype=torch.int64, device=sh.device), None)
         refine = sh.refine_fp32 and shadow is not None
+        status = None
         if top_k > nat.MAX_K:
             s, i = self._topk_large(sh, q32, slab, scales, shadow if refine else None, n, top_k)
         else:
@@ -359,11 +414,17 @@ class VectorStore:
             s, i = nat.cosine_topk(q16, slab, n, sh.dim, k_scan, slab_type=sh.slab_type, scales=scales,
                                    workspace=sh.workspace(nq, k_scan, n))
             if refine:
+                # fp32 re-rank of the k_scan candidates + the proof that no un-fetched row can reach the list; queries
+                # without proof are made exact on the device (one more sweep for them; a no-op launch otherwise)
                 qn = torch.nn.functional.normalize(q32, p=2, dim=1, eps=1e-12).contiguous()
-                s, i = nat.refine_f32(qn, shadow, n, 0, i, top_k)
+                cap = cap or self.exact_cap
+                ws = sh.exact_workspace(nq, cap)
+                s, i, status = nat.refine_f32_cert(qn, q16, shadow, n, 0, i, s, top_k, sh.row_err_max(), sh.slab_type, ws, cap)
+                if self._escalates(sh):
+                    nat.escalate_exact(qn, q16, slab, shadow, n, 0, top_k, s, i, status, ws, cap, scales=scales)
         if row_map is not None:
             i = torch.where(i >= 0, row_map[i.clamp(min=0)], i)
-        return s, i
+        return s, i, status
 
     def _topk_large(self, sh: _Shard, q32, slab, scales, shadow, n: int, top_k: int):
         """top_k above the scan kernels' limit (the reference accepts any n_results, rag/indexing.py:152-153):
@@ -420,6 +481,31 @@ class VectorStore:
             with torch.cuda.device(sh.device):
                 q = q32 if q32.device == sh.device else q32.to(sh.device, non_blocking=True)
                 parts.append(self._search_shard(sh, q, top_k, allowed_t))
+        # certificate bookkeeping (the one host wait of a refined search; search_batch reads the results right after anyway):
+        # status 2 = an escalated query's band held more rows than the list -- repeat that shard with a longer list
+        tally = {"queries": nq, "certified": 0, "escalated": 0, "unproven": 0}
+        worst = None
+        for g, sh in enumerate(col.shards):
+            if parts[g][2] is None:
+                continue
+            st = parts[g][2].cpu().numpy()
+            cap = self.exact_cap
+            while (st == 2).any() and cap < nat.EXACT_MAX_CAP:
+                cap = min(nat.EXACT_MAX_CAP, cap * 4)
+                with torch.cuda.device(sh.device):
+                    q = q32 if q32.device == sh.device else q32.to(sh.device)
+                    parts[g] = self._search_shard(sh, q, top_k, allowed_t, cap=cap)
+                st = parts[g][2].cpu().numpy()
+            if (st == 2).any():
+                logger.warning(f"{int((st == 2).sum())} queries have more than {nat.EXACT_MAX_CAP} rows within the error band of "
+                               f"their top-{top_k} (near-identical chunks): their lists are the fp32 re-rank of the over-fetch, unproven")
+            if not self._escalates(sh):
+                st = np.where(st == 1, 2, st)          # not escalated: unproven
+            worst = st if worst is None else np.maximum(worst, st)
+        if worst is not None:          # a query counts once: by its worst shard
+            tally.update(certified=int((worst == 0).sum()), escalated=int((worst == 1).sum()), unproven=int((worst == 2).sum()))
+            self.last_exactness = tally
+        parts = [(s_, i_) for s_, i_, _ in parts]
         if len(parts) > 1:             # one process, N devices: partial lists to the first device, merge there
             dev0 = col.device
             with torch.cuda.device(dev0):

@@ -48,9 +48,12 @@ int crs_padded_dim(int dim);
  * identity on already-normalised encoder output (rag/embedding.py:69).  For CRS_SLAB_I8,
  * `scales` (dev fp32, one per slab row) receives max|x|/127 of the normalised row.
  * `shadow_f32` (dev, stride `dim`, may be NULL) receives the normalised fp32 rows for exact
- * re-scoring. */
+ * re-scoring.
+ * `row_err_max` (dev, ONE fp32 that the caller zeroed when it created the slab; may be NULL) is raised to the
+ * largest |stored row - normalised fp32 row|_2 seen so far (the stored row being fp16, or int8 * scale):
+ * the measured row term of the exactness certificate below (ABI 3). */
 int crs_slab_append_f32(const float* emb_dev, int64_t n, int dim, int slab_type, void* slab_dev,
-                        float* scales_dev, float* shadow_f32_dev, int64_t row0, void* stream);
+                        float* scales_dev, float* shadow_f32_dev, int64_t row0, float* row_err_max_dev, void* stream);
 
 /* Query side of the same conversion: fp32 [nq, dim] -> normalised fp16 [nq, crs_row_elems(dim, slab_type)]. */
 int crs_queries_to_f16(const float* q_dev, int nq, int dim, int slab_type, void* q16_dev, void* stream);
@@ -92,6 +95,36 @@ int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_d
 int crs_refine_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
                    int64_t id_base, const int64_t* cand_ids_dev, int k_in, int k_out,
                    float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* ---- exactness certificate + escalation (ABI 3; csrc/exact.hip holds the derivation) ---------------------
+ * The reference's store keeps and ranks fp32 rows (rag/indexing.py:114-119,171-176); north_star asks for
+ * identical doc-id top-k sets.  crs_refine_f32_cert is crs_refine_f32 plus a per-query PROOF that the re-ranked
+ * k_out are the fp32 top-k_out of all n_rows rows, not only of the k_in fetched ones:
+ *     status[i] = 0   certified: k_out-th fp32 score > (k_in-th slab score) + eps_i, where eps_i bounds
+ *                     |slab score - fp32 score| for query i over every row of the shard (from |q16_i - q32_i|_2,
+ *                     measured here, and row_err_max = the value crs_slab_append_f32 tracked; pass a negative
+ *                     number to use the analytic worst case crs_exact_row_error_bound instead)
+ *     status[i] = 1   not certified (near-ties deeper than the over-fetch, e.g. near-duplicate chunks)
+ * cand_scores [nq, k_in] are the slab scores crs_cosine_topk returned with cand_ids; q16 [nq, crs_row_elems] is
+ * the query block that scan read, q32 [nq, dim] the unit fp32 queries.
+ * crs_escalate_exact then makes every status-1 query exact on the same stream, with no host round trip: one more
+ * sweep of the slab lists every row whose slab score is >= (k_out-th fp32 score so far) - eps_i (no row of the true
+ * top-k can score lower), and the list is re-ranked in fp32; out_scores / out_ids of those queries are overwritten,
+ * certified queries are left alone, and both kernels return at once when nothing is to do (so the call can sit in a
+ * captured graph).  A list longer than `cap` rows leaves status[i] = 2: call again with a larger cap
+ * (<= CRS_EXACT_MAX_CAP).  Workspace: crs_exact_workspace_bytes(nq, cap) bytes, written by crs_refine_f32_cert and
+ * consumed by crs_escalate_exact (same nq, cap). */
+#define CRS_EXACT_MAX_CAP 13312
+size_t crs_exact_workspace_bytes(int nq, int cap);
+float crs_exact_row_error_bound(int dim, int slab_type);
+int crs_refine_f32_cert(const float* q32_dev, const void* q16_dev, int nq, int dim, int slab_type, const float* shadow_dev,
+                        int64_t n_rows, int64_t id_base, const int64_t* cand_ids_dev, const float* cand_scores_dev, int k_in,
+                        int k_out, float row_err_max, float* out_scores_dev, int64_t* out_ids_dev, int32_t* status_dev,
+                        void* exact_ws_dev, size_t exact_ws_bytes, int cap, void* stream);
+int crs_escalate_exact(const float* q32_dev, const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,
+                       const float* scales_dev, const float* shadow_dev, int64_t n_rows, int64_t id_base, int k_out,
+                       float* out_scores_dev, int64_t* out_ids_dev, int32_t* status_dev, void* exact_ws_dev,
+                       size_t exact_ws_bytes, int cap, void* stream);
 
 /* ---- one-collective exchange (ONE all-gather per query batch) ------------------
  * A rank's per-shard result travels as one contiguous "wire block":

@@ -69,14 +69,37 @@ def _order(scores: np.ndarray, ids: np.ndarray) -> np.ndarray:
     return np.lexsort((ids, -scores.astype(np.float64)))
 
 
+def _select_block(cat_s: np.ndarray, cat_i: np.ndarray, kk: int):
+    """Per row the kk best of (cat_s, cat_i) in (score desc, id asc) order, vectorised over the rows.
+    Precondition (kept by cosine_topk_ref): within a row, equal scores appear in ascending id order from left to
+    right -- so among ties the left-most entries are the ones to keep and a stable sort finishes the order."""
+    nq, m = cat_s.shape
+    if m <= kk:
+        o = np.argsort(-cat_s.astype(np.float64), axis=1, kind="stable")
+        return np.take_along_axis(cat_s, o, 1), np.take_along_axis(cat_i, o, 1)
+    kth = np.partition(cat_s, m - kk, axis=1)[:, m - kk]              # the kk-th largest value per row (O(m))
+    rows, cols = np.nonzero(cat_s >= kth[:, None])                    # row-major: cols ascending inside a row; >= kk per row
+    sc = cat_s[rows, cols]
+    o = np.lexsort((cols, -sc.astype(np.float64), rows))              # row, then score desc, then position (= id) asc
+    rows, cols, sc = rows[o], cols[o], sc[o]
+    first = np.searchsorted(rows, np.arange(nq))                      # start of every row's run
+    take = (first[:, None] + np.arange(kk)[None, :]).reshape(-1)
+    return sc[take].reshape(nq, kk), cat_i[rows[take], cols[take]].reshape(nq, kk)
+
+
 def cosine_topk_ref(q: np.ndarray, slab: np.ndarray, k: int, *, scales: np.ndarray | None = None,
-                    id_base: int = 0, block: int = 1 << 16, accumulate=np.float32):
+                    id_base: int = 0, block: int = 1 << 16, accumulate=np.float32, timing: dict | None = None):
     """Exact top-k inner product of ``q[nq,d]`` against ``slab[n,d]`` (rows are unit vectors,
     so the inner product is the cosine).  Inputs are taken *as stored* (fp16 / int8) and
     widened; ``scales`` (fp32 per row) multiplies int8 rows' dot products.
 
+    Blocked: scores of a row block (BLAS sgemm), then per query the k best of (running list + block) --
+    an O(block) partition to the k-th value, ties resolved (score desc, id asc) on the few survivors.
+    ``timing`` (optional dict) receives the seconds spent in 'gemm' and in 'select'.
+
     Returns (scores fp32 [nq,k], ids int64 [nq,k]); slots beyond ``n`` hold (-inf, -1).
     """
+    import time
     q = np.asarray(q)
     nq = q.shape[0]
     n = slab.shape[0]
@@ -84,31 +107,24 @@ def cosine_topk_ref(q: np.ndarray, slab: np.ndarray, k: int, *, scales: np.ndarr
     best_s = np.full((nq, 0), NEG_INF, dtype=np.float32)
     best_i = np.zeros((nq, 0), dtype=np.int64)
     qa = q.astype(accumulate)
+    t_gemm = t_sel = 0.0
     for lo in range(0, n, block):
         hi = min(n, lo + block)
+        t0 = time.perf_counter()
         s = qa @ slab[lo:hi].astype(accumulate).T
         if scales is not None:
             s = s * scales[lo:hi].astype(accumulate)[None, :]
-        s = s.astype(np.float32)
-        ids = np.arange(lo, hi, dtype=np.int64)
+        s = s.astype(np.float32, copy=False)
+        t1 = time.perf_counter()
+        # running list first (ids < lo, sorted score desc / id asc), then the block in id order: ties ascend left to right
         cat_s = np.concatenate([best_s, s], axis=1)
-        cat_i = np.concatenate([best_i, np.broadcast_to(ids, (nq, hi - lo))], axis=1)
-        if cat_s.shape[1] > 4 * max(kk, 1):
-            # cheap prefilter: keep everything >= the kk-th largest value (ties kept)
-            kth = np.partition(cat_s, cat_s.shape[1] - kk, axis=1)[:, cat_s.shape[1] - kk]
-            new_s, new_i = [], []
-            for r in range(nq):
-                m = cat_s[r] >= kth[r]
-                rs, ri = cat_s[r][m], cat_i[r][m]
-                o = _order(rs, ri)[:kk]
-                new_s.append(rs[o]); new_i.append(ri[o])
-            best_s = np.stack(new_s); best_i = np.stack(new_i)
-        else:
-            new_s, new_i = [], []
-            for r in range(nq):
-                o = _order(cat_s[r], cat_i[r])[:kk]
-                new_s.append(cat_s[r][o]); new_i.append(cat_i[r][o])
-            best_s = np.stack(new_s); best_i = np.stack(new_i)
+        cat_i = np.concatenate([best_i, np.broadcast_to(np.arange(lo, hi, dtype=np.int64), (nq, hi - lo))], axis=1)
+        best_s, best_i = _select_block(cat_s, cat_i, kk)
+        t_gemm += t1 - t0
+        t_sel += time.perf_counter() - t1
+    if timing is not None:
+        timing["gemm"] = timing.get("gemm", 0.0) + t_gemm
+        timing["select"] = timing.get("select", 0.0) + t_sel
     out_s = np.full((nq, k), NEG_INF, dtype=np.float32)
     out_i = np.full((nq, k), -1, dtype=np.int64)
     out_s[:, :kk] = best_s

@@ -105,7 +105,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert declared == set(nat.exported_symbols()), "binding table and headers disagree"
-    assert lib.crs_abi_version() == 2
+    assert lib.crs_abi_version() == 3
     assert [lib.crs_padded_dim(d) for d in (1, 100, 128, 384, 768, 1000)] == [128, 128, 128, 384, 768, 1024]
 
 
@@ -116,7 +116,7 @@ def test_torch_custom_ops_are_registered():
     from rag import _native as nat
     ops = nat.ops()
     for name in ("slab_append", "queries_to_f16", "cosine_topk", "cosine_topk_out", "refine_f32", "refine_f32_out",
-                 "merge_topk", "merge_topk_out", "merge_topk_wire_out", "encoder_forward"):
+                 "refine_f32_cert_out", "escalate_exact", "merge_topk", "merge_topk_out", "merge_topk_wire_out", "encoder_forward"):
         assert hasattr(ops, name), name
     schema = str(torch.ops.crs.cosine_topk.default._schema)
     assert "Tensor q16, Tensor slab, Tensor? scales, int n_rows, int dim, int k, int id_base" in schema
@@ -133,7 +133,15 @@ def test_argument_validation_without_gpu():
     assert lib.crs_scan_workspace_bytes(4, 384, 65, 1000, ctypes.byref(out)) == -1
     assert b"k must be" in lib.crs_last_error()
     assert lib.crs_merge_topk(None, None, 1, 1, 1, 1, None, None, None) == -1
-    assert lib.crs_slab_append_f32(None, 5, 384, 7, None, None, None, 0, None) == -1
+    assert lib.crs_slab_append_f32(None, 5, 384, 7, None, None, None, 0, None, None) == -1
+    # exactness workspace: [thr | count | lists], and the analytic row-error bounds (fp16: 2^-11 relative; int8: 1/254 per element)
+    assert lib.crs_exact_workspace_bytes(64, 1024) == 2 * 256 + 64 * 1024 * 8
+    assert lib.crs_exact_workspace_bytes(0, 1024) == 0
+    assert 4.88e-4 < lib.crs_exact_row_error_bound(384, 0) < 4.95e-4
+    assert abs(lib.crs_exact_row_error_bound(768, 1) - 768 ** 0.5 / 254) < 1e-4
+    assert lib.crs_refine_f32_cert(None, None, 4, 384, 0, None, 100, 0, None, None, 16, 10, 0.0, None, None, None, None, 0, 1024, None) == -1
+    assert lib.crs_escalate_exact(None, None, 4, 384, 0, None, None, None, 100, 0, 10, None, None, None, None, 0, 70000, None) == -1
+    assert b"cap must be" in lib.crs_last_error()
 
 
 def test_no_cpu_fallback_without_gpu():
