@@ -6,13 +6,15 @@ torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
 One query BATCH through the retrieve path, everything resident in HBM:
   query encoder forward (token ids [Qb, 16] -> fp32 sentence embeddings + the scan's fp16 query block)
-  -> exact cosine scan of this rank's slab shard, over-fetching k' = 16 candidates per query
+  -> exact cosine scan of this rank's slab shard, over-fetching k' = 32 candidates per query
   -> per-workgroup list merge + tile refine -> fp32 re-rank of the k' candidates against the fp32 shadow
-     of the shard (the ranking the reference's fp32 ChromaDB collection gives), best k = 10 written
-     straight into this rank's wire block
+     of the shard (the ranking the reference's fp32 ChromaDB collection gives) WITH a per-query exactness
+     certificate (csrc/exact.hip), unproven queries escalated on the device inside the same graph (fp16
+     slabs; int8 stays empirical), best k = 10 written straight into this rank's wire block
   -> (N > 1) ONE RCCL all-gather of the wire blocks + k-way merge on every rank.
-A STEP is S such batches in flight (S = --streams, each with its own buffers), so the timed region is steady state
-whatever --steps is; queries per step = S x Qb.  --lanes: every batch wholly on its own HIP stream ("batch"), or encoder
+A STEP is S such batches in flight (S = --streams, each with its own buffers and its OWN 64 queries), so the timed region is
+steady state whatever --steps is; queries per step = S x Qb.  The batch, its lanes and its hipGraphs are the library's
+(rag/_engine.py RetrievalEngine -- the object ContextRetriever.retrieve_batch drives); bench.py only feeds it token ids.  --lanes: every batch wholly on its own HIP stream ("batch"), or encoder
 forwards on encoder lane(s) and searches on search lane(s), tied by events ("split": C4-class scans; see main()).
 
 Workloads (BASELINE.json configs; --workload):
@@ -29,8 +31,10 @@ behaviour (fixed 1.25M-row shard and Qb queries PER RANK; queries are all-gather
 
 The encoder has the architecture BASELINE.json names for the workload (all-MiniLM-L6-v2 for the 384-d
 configs, bge-base-en-v1.5 for the 768-d ones) with seeded random weights and synthetic token ids (no
-checkpoints offline).  Recall@10 is measured against the exact ranking of the UNQUANTISED fp32 rows
-(fp64 accumulation), not against the quantised slab.
+checkpoints offline).  Recall@10 is measured, untimed, on >= 8192 distinct queries run through the same engine, against the
+exact ranking of the UNQUANTISED fp32 rows (fp64 accumulation), not against the quantised slab; the line carries the sample
+size, the certified fraction and the number of escalated queries.  --through-pipeline times the plugin surface instead
+(texts -> RAGPipeline.retrieve_batch -> lists of dicts).
 """
 from __future__ import annotations
 
@@ -57,7 +61,7 @@ WORKLOADS = {
 }
 ENC_WORKLOADS = {"enc-minilm": ("minilm", 256, 256), "enc-bge": ("bge", 64, 512)}   # (arch, chunks per batch, tokens per chunk)
 QUERY_TOKENS = 16
-K_SCAN = 16               # candidates the scan over-fetches for the fp32 re-rank
+K_SCAN = 32               # candidates the scan over-fetches for the fp32 re-rank (VectorStore's default refine_overfetch)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TF = {"f16": 2500.0, "i8": 5000.0}
 
@@ -176,6 +180,88 @@ def bench_encoder(args, torch, nat, dev, rank, world, dist):
             "cpu_baseline": None}), flush=True)
 
 
+def bench_pipeline(args, torch, nat, dev):
+    """--through-pipeline: the PLUGIN SURFACE timed the way the reference's harness times it
+    (/root/reference/evaluation/retrieval/benchmark.py:241-247: perf_counter around rag_pipeline.retrieve(question)), at
+    BASELINE batch sizes through the additive batched entry: texts -> RAGPipeline.retrieve_batch -> lists of dicts.
+    Host tokenisation, the result D2H, the sidecar lookup and ContextRetriever's scoring / rerank / MMR are all inside
+    the timed call.  Two retrieval configs: (rerank, diversity) off, and the reference's defaults on (config.json:20-25)."""
+    import logging
+    import numpy as np
+    logging.disable(logging.WARNING)
+    from rag import RAGPipeline
+    from rag.chunking import Chunk
+    rows, dim, qb, k, slab_kind, enc_name, _ = WORKLOADS[args.workload]
+    if enc_name != "minilm" or slab_kind != "f16":
+        sys.exit("--through-pipeline runs the MiniLM fp16 workloads (c2, c4)")
+    if args.pipeline_rows > 0:
+        rows = args.pipeline_rows
+    rng = np.random.default_rng(0)
+    words = ("retrieval augmented generation language model quantization weights perplexity attention embedding cosine similarity "
+             "vector index chunk context answer question compression memory latency throughput accuracy benchmark kernel").split()
+
+    class Stub:
+        def generate(self, prompt, **kw):
+            return "n/a"
+
+    results = []
+    for label, rcfg in (("rerank off, diversity off", {"top_k": k, "similarity_threshold": 0.0, "rerank": False, "diversity_penalty": 0.0}),
+                        ("rerank on, diversity_penalty 0.1 (reference defaults)", {"top_k": k, "similarity_threshold": 0.0, "rerank": True, "diversity_penalty": 0.1})):
+        cfg = {"embedding": {"model_name": "synthetic:minilm", "device": "cuda", "batch_size": 64, "normalize": True},
+               "retrieval": dict(rcfg, batch_queries=qb), "vector_store": {"collection_name": "pipe"}}
+        p = RAGPipeline(cfg)
+        p.setup(Stub())
+        # index: synthetic unit embeddings straight into the store's slab (encoding 10 M chunk texts is the enc-* workload),
+        # with a ~40-word document per row in the host sidecars
+        t_index = time.perf_counter()
+        g = torch.Generator(device=dev); g.manual_seed(1234)
+        base_docs = [" ".join(rng.choice(words, size=40)) for _ in range(4096)]
+        for lo in range(0, rows, 250_000):
+            m = min(250_000, rows - lo)
+            emb = torch.randn((m, dim), generator=g, device=dev)
+            chunks = [Chunk(text=base_docs[(lo + r) & 4095] + f" {lo + r}", chunk_id=f"chunk_{lo + r}", start_char=0, end_char=1) for r in range(m)]
+            p.vector_store.create_index(chunks, emb)
+        torch.cuda.synchronize()
+        t_index = time.perf_counter() - t_index
+        n_q = qb * max(1, args.streams)
+        queries = [" ".join(rng.choice(words, size=int(rng.integers(5, 12)))) for _ in range(n_q)]
+        for _ in range(max(1, args.warmup)):
+            p.retrieve_batch(queries)
+        lat = []
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            out = p.retrieve_batch(queries)
+            lat.append(time.perf_counter() - t0)
+        # the same queries one at a time through the unchanged per-query entry (what the reference's loop does)
+        t0 = time.perf_counter()
+        for q in queries[:64]:
+            p.retrieve(q)
+        single_ms = (time.perf_counter() - t0) / 64 * 1e3
+        # host / device split of one call: tokenisation, engine (device + readback), post-processing incl. the MMR encoder pass
+        r = p.retriever
+        t0 = time.perf_counter(); toks = p.embedding_model.tokenize(queries); t_tok = time.perf_counter() - t0
+        t0 = time.perf_counter(); hits = r._search_many(queries, k * 2 if r.rerank else k); t_search = time.perf_counter() - t0
+        med = sorted(lat)[len(lat) // 2]
+        results.append({"retrieval_config": label, "queries_per_call": n_q, "queries_per_batch": qb, "corpus_rows": rows,
+                        "queries_per_s": round(n_q / med, 1), "ms_per_call_median": round(med * 1e3, 3),
+                        "ms_per_call_min": round(min(lat) * 1e3, 3), "single_query_retrieve_ms": round(single_ms, 3),
+                        "split_ms": {"tokenize": round(t_tok * 1e3, 3), "tokenize_plus_engine_search_and_readback": round(t_search * 1e3, 3),
+                                     "post_processing_incl_mmr_encoder_pass": round(max(med - t_search, 0.0) * 1e3, 3)},
+                        "chunks_returned_first_query": len(out[0]), "exactness": dict(p.vector_store.last_exactness),
+                        "index_s": round(t_index, 2)})
+        del p
+        torch.cuda.empty_cache()
+    best = results[0]
+    print(json.dumps({
+        "metric": "queries/sec through the plugin surface (texts -> RAGPipeline.retrieve_batch -> lists of dicts)",
+        "value": best["queries_per_s"], "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": best["ms_per_call_median"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16 x f16 -> f32", "data": "synthetic",
+        "config": {"workload": args.workload + " through RAGPipeline", "timing": "time.perf_counter around the call (reference: evaluation/retrieval/benchmark.py:241-247)",
+                   "encoder": "all-MiniLM-L6-v2 shape, seeded random weights, hash tokenizer", "results": results},
+        "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +295,15 @@ def main():
                          "encodes Qb / N queries and the embeddings are all-gathered first (two collectives; the encoder's kernels "
                          "then cover 1/N of the CUs, so the chains of the in-flight batches run side by side).  auto = sharded "
                          "from 4 GPUs on (when N divides the batch), replicated below")
+    ap.add_argument("--k-scan", type=int, default=0, help="candidates the scan over-fetches for the fp32 re-rank (0: 32)")
+    ap.add_argument("--exact", default="auto", choices=("auto", "on", "off"),
+                    help="in-stream escalation of queries whose list the certificate could not prove (auto: fp16 slabs on, int8 empirical)")
+    ap.add_argument("--recall-queries", type=int, default=8192,
+                    help="distinct queries the (untimed) recall / certificate check runs through the timed path's engine")
+    ap.add_argument("--through-pipeline", action="store_true",
+                    help="time the PLUGIN SURFACE instead: texts -> ContextRetriever.retrieve_batch -> list of dicts "
+                         "(workloads c2 / c4), perf_counter around the call as evaluation/retrieval/benchmark.py:241-247 does")
+    ap.add_argument("--pipeline-rows", type=int, default=0, help="--through-pipeline: override the corpus rows")
     ap.add_argument("--proxy-encode-shard", type=int, default=0,
                     help="diagnostic, N = 1: encode only Qb / W queries per batch and tile them W times in place of the all-gather "
                          "(what one rank of a W-GPU step with --encode sharded executes, minus the collectives)")
@@ -250,6 +345,10 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.through_pipeline:
+        bench_pipeline(args, torch, nat, dev)
+        return
+
     corpus_rows, dim, qb, k, slab_kind, enc_name, weak_rows = WORKLOADS[args.workload]
     if args.queries > 0:
         qb = args.queries
@@ -258,229 +357,105 @@ def main():
     strong = args.scaling == "strong"
     if strong:
         lo_row, hi_row = _shard.shard_slice(corpus_rows, world, rank)
-        rows, id_base, nq_all = hi_row - lo_row, lo_row, qb
+        rows, id_base = hi_row - lo_row, lo_row
     else:
-        rows, id_base, nq_all = weak_rows, rank * weak_rows, qb * world
+        rows, id_base = weak_rows, rank * weak_rows
         corpus_rows = weak_rows * world
     # auto: sharded from 4 GPUs on.  Measured on one GPU as what a rank executes minus the collectives (tools/ab_shard_enc.sh,
     # --proxy-encode-shard): per batch 0.313 -> 0.261 ms at the 8-GPU shard size, 0.466 -> 0.414 at 4, 0.775 -> 0.749 at 2 --
-    # at 2 GPUs the gain is less than a second collective is expected to cost
+    # at 2 GPUs the gain is less than a second collective is expected to cost.  PROVISIONAL: the proxy excludes the collective
+    # this adds; no N > 1 RCCL run exists yet
     want_shard = args.encode == "sharded" or (args.encode == "auto" and world >= 4)
-    shard_w = world if (strong and multi and want_shard and qb % world == 0) else 1
-    if not multi and args.proxy_encode_shard > 1 and qb % args.proxy_encode_shard == 0:
-        shard_w = args.proxy_encode_shard
-    q_loc = qb // shard_w                      # queries THIS rank encodes per batch
-    gather_q = (multi and (not strong or shard_w > 1)) or (not multi and shard_w > 1)
     refine = not args.no_refine
-    k_scan = max(k, K_SCAN) if refine else k
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
     pd = nat.padded_dim(dim, slab_type)
-    # Lane layout (see the comment at the batch loop).  'split' only pays when the scan is long against the encoder chain
-    # AND the encoder's kernels can run beside the scan's workgroups (2 x 48 KB of a CU's 160 KB of LDS are taken): the
-    # MiniLM-class query encoder has such a form (K walked in 128-column chunks, QKV projection and attention as separate
-    # launches: <= 48 KB each); measured per 64-query batch, same call, one lane per batch -> split: C4 1.40 - 1.42 ->
-    # 1.31 - 1.39 ms, one rank of a 4 / 8-GPU step 0.470 -> 0.462 / 0.265 -> 0.252 ms; bge-base (C5 / C3) and C2 lose
-    # with it (tools/ab_lanes*.sh).
-    scan_bytes = rows * pd * (1 if slab_type == nat.SLAB_I8 else 2)
-    pipelined = args.lanes == "split" or (args.lanes == "auto" and enc_name == "minilm" and scan_bytes >= (512 << 20))
-    if pipelined:
-        os.environ.setdefault("CRS_PANEL_KC", "128")
-        os.environ.setdefault("CRS_ENC_QKVATTN", "0")
+    k_scan_cfg = args.k_scan if args.k_scan > 0 else K_SCAN
 
     # ---- index build (untimed): synthetic embeddings -> slab shard (+ fp32 shadow) in HBM through the product path
     slab = torch.empty((rows, pd), dtype=torch.int8 if slab_type == nat.SLAB_I8 else torch.float16, device=dev)
     scales = torch.empty(rows, dtype=torch.float32, device=dev) if slab_type == nat.SLAB_I8 else None
     shadow = torch.empty((rows, dim), dtype=torch.float32, device=dev)   # unquantised rows: refine operand AND ground truth
+    row_err = torch.zeros(1, dtype=torch.float32, device=dev)            # tracked |stored row - fp32 row|_2 maximum
     t_build = time.perf_counter()
     for lo, x in synth_rows(torch, rows, dim, 1234 + rank, dev):
-        nat.slab_append_f32(x, slab, lo, slab_type, scales=scales, shadow=shadow)
+        nat.slab_append_f32(x, slab, lo, slab_type, scales=scales, shadow=shadow, row_err=row_err)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
     # ---- query encoder (architecture per BASELINE config, seeded random weights) + synthetic token ids.
-    # Everything in the timed path comes from the product package; oracle/ is imported further down,
-    # inside the cpu_baseline leg only.
+    # Everything in the timed path comes from the product package (rag/_engine.py drives it); oracle/ is imported
+    # further down, inside the cpu_baseline leg only.
     from rag._encoder import HipEncoder, ModelShape
+    from rag._engine import RetrievalEngine, ShardView
     from rag.embedding import _KNOWN, synthetic_weights
     arch = _KNOWN["all-minilm-l6-v2" if enc_name == "minilm" else "bge-base-en-v1.5"]
     shape = ModelShape(ln_eps=1e-12, **arch)
     enc_w = synthetic_weights(shape, seed=7)
     enc = HipEncoder(shape, enc_w, device=dev)
-    rng = np.random.default_rng(4321 + (0 if strong else rank))      # strong: every rank holds the SAME global batch
-    ids_h = rng.integers(1000, shape.vocab_size, size=(qb, QUERY_TOKENS)).astype(np.int32)
-    ids_h[:, 0], ids_h[:, -1] = 101, 102                      # [CLS] ... [SEP], no padding
-    mask_h = np.ones((qb, QUERY_TOKENS), dtype=np.int32)
-    ids_full = torch.from_numpy(ids_h).to(dev)
-    lens_full = torch.from_numpy(mask_h.sum(1).astype(np.int32)).to(dev)
-    q32 = enc.forward(ids_full, lens_full).clone()            # fp32 unit rows [qb, dim] (planting, diagnostics)
-    enc_lo = (rank if multi else 0) * q_loc if shard_w > 1 else 0
-    ids_d, lens_d = ids_full[enc_lo:enc_lo + q_loc].contiguous(), lens_full[enc_lo:enc_lo + q_loc].contiguous()
-    # plant a near neighbour of every even query (50 % planted); strong: query 2p lives on rank p % world
+    n_ctx = max(1, args.streams)
+    # Query set: R distinct queries (>= --recall-queries, a whole number of batches; the first n_ctx batches are the ones the
+    # timed loop keeps in flight).  strong: every rank holds the SAME global batches; weak: per-rank queries.
+    n_batches = max(n_ctx, -(-max(args.recall_queries, 1) // qb)) if strong else n_ctx
+    rng = np.random.default_rng(4321 + (0 if strong else rank))
+    ids_all = rng.integers(1000, shape.vocab_size, size=(n_batches, qb, QUERY_TOKENS)).astype(np.int32)
+    ids_all[:, :, 0], ids_all[:, :, -1] = 101, 102                      # [CLS] ... [SEP], no padding
+    lens_h = np.full(qb, QUERY_TOKENS, dtype=np.int32)
+    ids_dev_all = torch.from_numpy(ids_all).to(dev)
+    lens_dev = torch.from_numpy(lens_h).to(dev)
+    q32_all = torch.empty((n_batches, qb, dim), dtype=torch.float32, device=dev)   # fp32 unit rows (planting, ground truth)
+    for b in range(n_batches):
+        q32_all[b] = enc.forward(ids_dev_all[b], lens_dev)
+    # plant a near neighbour of every even query (50 % planted); strong: planted query p lives on rank p % world
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
-    mine = [p for p in range(0, qb, 2) if (not strong) or ((p // 2) % world == rank)]
+    flat_q = q32_all.view(-1, dim)
+    mine = [p for p in range(0, flat_q.shape[0], 2) if (not strong) or ((p // 2) % world == rank)]
     if mine and rows > len(mine):
         j = torch.randperm(rows, generator=g, device=dev)[: len(mine)]
-        planted = q32[mine] + 0.1 * torch.randn((len(mine), dim), generator=g, device=dev)
+        planted = flat_q[mine] + 0.1 * torch.randn((len(mine), dim), generator=g, device=dev)
         tmp = torch.empty((len(mine), pd), dtype=slab.dtype, device=dev)
         tmp_sc = torch.empty(len(mine), dtype=torch.float32, device=dev) if scales is not None else None
         tmp_sh = torch.empty((len(mine), dim), dtype=torch.float32, device=dev)
-        nat.slab_append_f32(planted.contiguous(), tmp, 0, slab_type, scales=tmp_sc, shadow=tmp_sh)
+        nat.slab_append_f32(planted.contiguous(), tmp, 0, slab_type, scales=tmp_sc, shadow=tmp_sh, row_err=row_err)
         slab[j] = tmp
         shadow[j] = tmp_sh
         if scales is not None:
             scales[j] = tmp_sc
+    view = ShardView(slab, scales, shadow, rows, dim, slab_type, id_base, float(row_err.item()))
 
-    class Ctx:
-        """Buffers of one in-flight query batch (a batch touches nothing outside its Ctx + read-only state)."""
-        def __init__(self):
-            self.q_out = torch.empty((q_loc, dim), dtype=torch.float32, device=dev)
-            self.q16 = torch.empty((q_loc, pd), dtype=torch.float16, device=dev)
-            self.enc_ws = torch.empty(enc.workspace_bytes(q_loc, QUERY_TOKENS), dtype=torch.uint8, device=dev)
-            self.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, k_scan, rows), dtype=torch.uint8, device=dev)
-            self.cand_s = torch.empty((nq_all, k_scan), dtype=torch.float32, device=dev)
-            self.cand_i = torch.empty((nq_all, k_scan), dtype=torch.int64, device=dev)
-            self.wire = nat.WireBlock(nq_all, k, dev, world, gather=multi)     # this rank's (ids | scores) block + the gathered blocks
-            self.graphs = None
-            if multi:
-                self.fin_s = torch.empty((nq_all, k), dtype=torch.float32, device=dev)
-                self.fin_i = torch.empty((nq_all, k), dtype=torch.int64, device=dev)
-            if gather_q:
-                self.q_all32 = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
-                self.q_all16 = torch.empty((nq_all, pd), dtype=torch.float16, device=dev)
+    def make_engine(do_refine, exact):
+        return RetrievalEngine(enc if not args.scan_only else None, view if do_refine else ShardView(slab, scales, None, rows, dim, slab_type, id_base),
+                               qb, QUERY_TOKENS, k, k_scan=k_scan_cfg, refine=do_refine, exact=exact, n_ctx=n_ctx, lanes=args.lanes,
+                               enc_lanes=args.enc_lanes, search_lanes=args.search_lanes, graphs=not args.no_graph,
+                               dist=dist if multi else None, world=world, rank=rank, queries_per_rank=not strong,
+                               encode_shard=(world if (strong and multi and want_shard) else 1),
+                               proxy_encode_shard=args.proxy_encode_shard, encode=not args.scan_only)
 
-    # A batch = device segments with the collectives between them; every segment reads and writes fixed buffers
-    # of its Ctx, so each is captured once into a hipGraph and replayed.
-    def seg_encode(c):      # token ids -> fp32 embeddings + the scan's fp16 query block
+    exact_mode = {"auto": "auto", "on": True, "off": False}[args.exact]
+    eng = make_engine(refine, exact_mode)
+    nq_all, q_loc, enc_lo, gather_q, k_scan = eng.nq_all, eng.q_loc, eng.enc_lo, eng.gather_q, eng.k_scan
+
+    def load_batch(i, b):          # tokens (or, --scan-only, embeddings) of query batch b into buffer set i
         if args.scan_only:
-            c.q_out.copy_(q32[enc_lo:enc_lo + q_loc])
-            nat.queries_to_f16(c.q_out, slab_type, out=c.q16)
+            eng.ctxs[i].q_out.copy_(q32_all[b, enc_lo:enc_lo + q_loc])
         else:
-            enc.forward(ids_d, lens_d, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=slab_type)
-
-    def seg_search(c, do_refine=refine):       # all queries of the batch x this rank's shard -> this rank's wire block
-        qa32 = c.q_all32 if gather_q else c.q_out
-        if gather_q:
-            if not multi:      # --proxy-encode-shard: the local queries tiled in place of the all-gather
-                c.q_all32.view(shard_w, q_loc, dim).copy_(c.q_out.unsqueeze(0).expand(shard_w, q_loc, dim))
-            nat.queries_to_f16(qa32, slab_type, out=c.q_all16)
-        qa16 = c.q_all16 if gather_q else c.q16
-        if do_refine:
-            nat.cosine_topk(qa16, slab, rows, dim, k_scan, slab_type=slab_type, scales=scales, id_base=id_base,
-                            workspace=c.ws, out_scores=c.cand_s, out_ids=c.cand_i)
-            nat.refine_f32(qa32, shadow, rows, id_base, c.cand_i, k, out_scores=c.wire.scores, out_ids=c.wire.ids)
-        else:
-            nat.cosine_topk(qa16, slab, rows, dim, k, slab_type=slab_type, scales=scales, id_base=id_base,
-                            workspace=c.ws, out_scores=c.wire.scores, out_ids=c.wire.ids)
-
-    def seg_merge(c):       # N > 1: the gathered wire blocks -> global top-k
-        nat.merge_topk_wire(c.wire.gathered, world, nq_all, k, k, out_scores=c.fin_s, out_ids=c.fin_i)
-
-    # segments of a batch, in order, each with the collective that follows it (N > 1) and the lane it runs on
-    # ("E": encoder lane, "S": search lane)
-    segs = [seg_encode, seg_search] + ([seg_merge] if multi else [])
-    lanes = ["E", "S", "S"][: len(segs)]
-    exchanges = [None] * len(segs)
-    if multi and gather_q:  # queries encoded in shards (or weak scaling: per-rank queries): embeddings gathered first
-        exchanges[0] = lambda c: dist.all_gather_into_tensor(c.q_all32, c.q_out)
-    if multi:               # the ONE exchange of a sharded search: every rank's wire block
-        exchanges[1] = lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)
-    n_exchanges = sum(1 for e in exchanges if e is not None)
+            eng.set_tokens(i, ids_dev_all[b, enc_lo:enc_lo + q_loc], lens_dev[:q_loc])
 
     def sync():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Throughput mode: S batches in flight, each with its own buffers (Ctx).  The GPU runs a process's streams on four
-    # hardware queues; a query-encoder forward is a chain of 38 dependent launches of a few microseconds each (latency,
-    # not work), a scan is one kernel that wants every byte of HBM bandwidth.  Round 1 / early round 2 gave every batch
-    # its own stream -- encoder chain, scan, merge, refine in one lane -- so a lane spent a third of its time inside an
-    # encoder chain and the scans of the other lanes did not always cover it (C4 batch 1.38 - 1.41 ms for a 1.28 ms scan).
-    # Now the lanes have ROLES: encoder forwards of upcoming batches run on the encoder lane(s), searches alternate
-    # between the search lanes (one's merge / refine tail under the other's scan), tied together by events per Ctx;
-    # the same kernels, the same work per batch, nothing skipped.  --lanes batch restores one lane per batch.
-    # For N > 1 the RCCL collectives between the segments are launched eagerly in batch order (every rank issues them in
-    # the same order; they are serialised on the process group's own stream).
-    n_ctx = max(1, args.streams)
-    use_graph = not args.no_graph
-    ctxs = [Ctx() for _ in range(n_ctx)]
-    if pipelined:
-        # measured (tools/ab_lanes.sh): two encoder lanes feed ONE search lane at every shard size (one encoder lane starves
-        # scans of <= 2.5 M rows: 0.41 against 0.25 ms per batch at 1.25 M).  On the whole 10 M-row corpus a second search
-        # lane (one scan's merge / refine tail under the next scan) is worth another 1 - 2 %, but then consecutive scans
-        # overlap and a per-kernel duration -- the roofline's denominator, the rocprof kernel average -- stops meaning
-        # "one scan"; with one search lane the scans run one after another (1.30 ms in the trace against 1.27 - 1.28 isolated).
-        n_enc = args.enc_lanes if args.enc_lanes > 0 else 2
-        n_srch = args.search_lanes if args.search_lanes > 0 else 1
-        enc_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_enc)]
-        srch_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_srch)]
-    else:
-        n_enc = n_srch = n_ctx
-        enc_lanes = srch_lanes = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)]
-    for c in ctxs:
-        c.ev_enc, c.ev_done = torch.cuda.Event(), torch.cuda.Event()
-    issued = [0]
-
-    def batch(c):
-        """Issue one batch: encode on an encoder lane, search (+ exchange + merge) on a search lane."""
-        b = issued[0]
-        issued[0] += 1
-        lane = {"E": enc_lanes[b % n_enc], "S": srch_lanes[b % n_srch]}
-        prev = None
-        for j, seg in enumerate(segs):
-            st = lane[lanes[j]]
-            with torch.cuda.stream(st):
-                if j == 0:
-                    st.wait_event(c.ev_done)          # the previous batch that used this Ctx is through (no-op before its first use)
-                elif st is not prev:
-                    st.wait_event(c.ev_enc)           # lane change: the encoder lane's output (and its collective) is complete
-                if c.graphs is not None:
-                    c.graphs[j].replay()
-                else:
-                    seg(c)
-                if exchanges[j] is not None:
-                    exchanges[j](c)
-                if j == 0:
-                    c.ev_enc.record(st)
-                if j == len(segs) - 1:
-                    c.ev_done.record(st)
-            prev = st
-        return (c.fin_s, c.fin_i) if multi else (c.wire.scores, c.wire.ids)
-
-    torch.cuda.synchronize()
-    for c in ctxs:
-        for _ in range(2):
-            batch(c)
-        torch.cuda.synchronize()
-        if use_graph:
-            # thread_local: with N > 1 the process group's watchdog thread polls events while we capture;
-            # only this thread's calls belong to the capture.  If a capture fails anyway, run eagerly.
-            try:
-                gl = []
-                for j, seg in enumerate(segs):
-                    st = (enc_lanes if lanes[j] == "E" else srch_lanes)[0]
-                    g_ = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
-                        seg(c)
-                    gl.append(g_)
-                c.graphs = gl
-            except Exception as exc:   # noqa: BLE001 -- report and keep going without graphs
-                print(f"[bench] hipGraph capture failed on rank {rank} ({exc!r}); launching eagerly", file=sys.stderr, flush=True)
-                use_graph = False
-                for cc in ctxs:
-                    cc.graphs = None
-                torch.cuda.synchronize()   # (no break: every rank must still run the same warm-up collectives)
+    # ---- the timed region: n_ctx DISTINCT query batches in flight, one step = one batch from every buffer set ----------
+    for i in range(n_ctx):
+        load_batch(i, i)
+    eng.warm_up()
     sync()
-
-    def run(n_steps):
-        for _ in range(n_steps):
-            for c in ctxs:
-                batch(c)
-
-    run(args.warmup)
+    for _ in range(args.warmup):
+        eng.step()
     sync()
     t0 = time.perf_counter()
-    run(args.steps)
+    for _ in range(args.steps):
+        eng.step()
     sync()
     dt = time.perf_counter() - t0
     if multi:
@@ -490,83 +465,127 @@ def main():
     q_per_step = nq_all * n_ctx
     ms_step = dt / args.steps * 1e3
     qps = q_per_step * args.steps / dt
+    timed_status = torch.stack([eng.outputs(i)[2] for i in range(n_ctx)]).clone()     # certificate outcome of the in-flight batches
 
-    # ---- correctness of the timed path (untimed): its final lists against the exact ranking of the UNQUANTISED
-    # fp32 rows of every shard (fp64 accumulation) -- catches quantisation loss as well as any mix-up of query
-    # order, id bases, wire layout or merge.
-    def gathered_queries():
-        if multi and gather_q:
-            qa = torch.empty((nq_all, dim), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(qa, ctxs[0].q_out.contiguous())
-            return qa
-        return ctxs[0].q_all32 if gather_q else ctxs[0].q_out
+    # ---- correctness of the timed path (untimed): EVERY query of the set through the same engine (same graphs, fresh token
+    # ids per batch), final lists against the exact ranking of the UNQUANTISED fp32 rows of every shard (fp64 accumulation)
+    # -- catches quantisation loss as well as any mix-up of query order, id bases, wire layout or merge.
+    def run_all(engine):
+        fs, fi, fst = [], [], []
+        for b0 in range(0, n_batches, n_ctx):
+            nb = min(n_ctx, n_batches - b0)
+            for i in range(nb):
+                if args.scan_only:
+                    engine.ctxs[i].q_out.copy_(q32_all[b0 + i, enc_lo:enc_lo + q_loc])
+                else:
+                    engine.set_tokens(i, ids_dev_all[b0 + i, enc_lo:enc_lo + q_loc], lens_dev[:q_loc])
+                engine.submit(i)
+            torch.cuda.synchronize()
+            for i in range(nb):
+                s_, i_, st_ = engine.outputs(i)
+                fs.append(s_.clone()); fi.append(i_.clone()); fst.append(st_.clone())
+        return torch.cat(fs), torch.cat(fi), torch.cat(fst)
 
-    fin_s, fin_i = batch(ctxs[0])           # (issues on its lanes)
-    torch.cuda.synchronize()
-    fin_s, fin_i = fin_s.clone(), fin_i.clone()
-    q_truth = gathered_queries()
-    gt_s, gt_i = exact_topk_f64(torch, q_truth, shadow, rows, k, id_base)
+    fin_s, fin_i, fin_st = run_all(eng)
+    if strong:
+        q_truth = flat_q
+    else:                           # weak scaling: the batch every rank searched = all ranks' queries, gathered
+        q_truth = torch.empty((n_batches, nq_all, dim), dtype=torch.float32, device=dev)
+        for b in range(n_batches):
+            dist.all_gather_into_tensor(q_truth[b], q32_all[b].contiguous()) if multi else q_truth[b].copy_(q32_all[b])
+        q_truth = q_truth.view(-1, dim)
+    nq_total = q_truth.shape[0]
+    gt_s = torch.empty((nq_total, k), dtype=torch.float64, device=dev)
+    gt_i = torch.empty((nq_total, k), dtype=torch.int64, device=dev)
+    for lo in range(0, nq_total, 1024):
+        gt_s[lo:lo + 1024], gt_i[lo:lo + 1024] = exact_topk_f64(torch, q_truth[lo:lo + 1024], shadow, rows, k, id_base)
     if multi:
-        all_s = torch.empty((world * nq_all, k), dtype=torch.float64, device=dev)
-        all_i = torch.empty((world * nq_all, k), dtype=torch.int64, device=dev)
+        all_s = torch.empty((world * nq_total, k), dtype=torch.float64, device=dev)
+        all_i = torch.empty((world * nq_total, k), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(all_s, gt_s.contiguous()); dist.all_gather_into_tensor(all_i, gt_i.contiguous())
-        all_s = all_s.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)
-        all_i = all_i.view(world, nq_all, k).permute(1, 0, 2).reshape(nq_all, world * k)   # rank-major = id-ascending
+        all_s = all_s.view(world, nq_total, k).permute(1, 0, 2).reshape(nq_total, world * k)
+        all_i = all_i.view(world, nq_total, k).permute(1, 0, 2).reshape(nq_total, world * k)   # rank-major = id-ascending
         o = torch.argsort(all_s, dim=1, descending=True, stable=True)[:, :k]
         gt_s, gt_i = torch.gather(all_s, 1, o), torch.gather(all_i, 1, o)
     rec_timed = recall_rows(fin_i, gt_i)
     recall_timed = float(rec_timed.mean().item())
+    # "identical id sets" can only be asked up to what fp32 resolves: the product (like the reference's fp32 store) ranks by
+    # fp32 dot products, this ground truth accumulates in fp64, and two rows within ~1e-7 of each other around rank k may
+    # swap.  A returned list is accepted as exact when every returned row (that this rank owns) scores, in fp64, at least
+    # the true k-th score minus 3e-7; anything else is a real miss.
+    own = (fin_i >= id_base) & (fin_i < id_base + rows)
+    loc = (fin_i - id_base).clamp(0, rows - 1)
+    s64 = torch.empty(fin_i.shape, dtype=torch.float64, device=dev)
+    for lo in range(0, nq_total, 2048):
+        s64[lo:lo + 2048] = (shadow[loc[lo:lo + 2048]].double() * q_truth[lo:lo + 2048].double().unsqueeze(1)).sum(-1)
+    kth64 = gt_s[:, k - 1:k]
+    exact_ok = ((~own) | (fin_i < 0) | (s64 >= kth64 - 3e-7)).all(dim=1) & ((fin_i >= 0).sum(1) == (gt_i >= 0).sum(1))
+    if multi:
+        eo = exact_ok.to(torch.int32)
+        dist.all_reduce(eo, op=dist.ReduceOp.MIN)
+        exact_ok = eo.bool()
+    exact_frac = float(exact_ok.float().mean().item())
     ids_identical = float((fin_i == gt_i).all(dim=1).float().mean().item())
+    sets_identical = float((rec_timed == 1.0).float().mean().item())
     score_err = float((fin_s.double() - gt_s).abs().max().item())
-    # the other mode, for the record (one untimed eager batch): plain fp16/int8 scan with k' = k, or the refined one
-    c0 = ctxs[0]
-    with torch.cuda.stream(srch_lanes[0]):
-        seg_encode(c0)
-        if multi and gather_q:
-            dist.all_gather_into_tensor(c0.q_all32, c0.q_out)
-        if refine:
-            seg_search(c0, do_refine=False)
-        else:
-            c0.cand_s = torch.empty((nq_all, max(k, K_SCAN)), dtype=torch.float32, device=dev)
-            c0.cand_i = torch.empty((nq_all, max(k, K_SCAN)), dtype=torch.int64, device=dev)
-            c0.ws = torch.empty(nat.scan_workspace_bytes(nq_all, dim, max(k, K_SCAN), rows), dtype=torch.uint8, device=dev)
-            qa16 = c0.q_all16 if gather_q else c0.q16
-            qa32 = c0.q_all32 if gather_q else c0.q_out
-            if gather_q:
-                if not multi:
-                    c0.q_all32.view(shard_w, q_loc, dim).copy_(c0.q_out.unsqueeze(0).expand(shard_w, q_loc, dim))
-                nat.queries_to_f16(qa32, slab_type, out=c0.q_all16)
-            nat.cosine_topk(qa16, slab, rows, dim, max(k, K_SCAN), slab_type=slab_type, scales=scales, id_base=id_base,
-                            workspace=c0.ws, out_scores=c0.cand_s, out_ids=c0.cand_i)
-            nat.refine_f32(qa32, shadow, rows, id_base, c0.cand_i, k, out_scores=c0.wire.scores, out_ids=c0.wire.ids)
-        if multi:
-            dist.all_gather_into_tensor(c0.wire.gathered, c0.wire.buf)
-            seg_merge(c0)
-        oth_s, oth_i = ((c0.fin_s, c0.fin_i) if multi else (c0.wire.scores, c0.wire.ids))
+    # certificate outcome over the whole set (this rank's shard; N > 1: summed over the ranks)
+    cert_counts = torch.tensor([(fin_st == 0).sum(), (fin_st == 1).sum(), (fin_st == 2).sum(), fin_st.numel()], dtype=torch.float64, device=dev)
+    if multi:
+        dist.all_reduce(cert_counts)
+    cert_counts = cert_counts.tolist()
+    # the other mode, for the record (untimed, same queries): the plain fp16 / int8 scan with k' = k, or the refined one
+    eng_other = make_engine(not refine, exact_mode)
+    eng_other.use_graph = False
+    eng_other.warm_up()
+    oth_s, oth_i, _ = run_all(eng_other)
     torch.cuda.synchronize()
     recall_other = float(recall_rows(oth_i, gt_i).mean().item())
     err_other = float((oth_s.double() - gt_s).abs().max().item())
+    del eng_other
     tol = 1e-5 if refine else (5e-3 if slab_type == nat.SLAB_I8 else 1e-3)
-    check_ok = bool(score_err < tol and recall_timed >= (0.999 if refine else 0.8))
-    recall_report = {"timed_path": round(recall_timed, 5),
-                     "timed_mode": (f"{slab_kind} scan k'={k_scan} + fp32 shadow re-rank" if refine else f"{slab_kind} scan only"),
-                     "queries_with_identical_ordered_ids": round(ids_identical, 5), "max_abs_score_err_vs_fp64": score_err,
-                     ("scan_only_no_refine" if refine else "with_fp32_refine"): round(recall_other, 5),
+    # with escalation on (fp16), every list is proven or made exact: demand identical id SETS for every query, not a mean
+    guaranteed = refine and eng.exact
+    check_ok = bool(score_err < tol and recall_timed >= (0.999 if refine else 0.8) and (not guaranteed or exact_frac == 1.0))
+    recall_report = {"timed_path": round(recall_timed, 6), "queries_checked": int(nq_total),
+                     "timed_mode": (f"{slab_kind} scan k'={k_scan} + fp32 shadow re-rank + exactness certificate"
+                                    + (" + in-stream escalation of unproven queries" if eng.exact else " (unproven queries NOT escalated: empirical)")
+                                    if refine else f"{slab_kind} scan only"),
+                     "queries_with_identical_id_sets": round(sets_identical, 6),
+                     "queries_exact_up_to_fp32_resolution": round(exact_frac, 6),
+                     "queries_with_identical_ordered_ids": round(ids_identical, 6), "max_abs_score_err_vs_fp64": score_err,
+                     "certified_frac": round(cert_counts[0] / max(cert_counts[3], 1), 6) if refine else None,
+                     "escalated": int(cert_counts[1]) if (refine and eng.exact) else 0,
+                     "unproven": (int(cert_counts[2]) if eng.exact else int(cert_counts[1] + cert_counts[2])) if refine else None,
+                     "escalated_in_timed_batches": int((timed_status == 1).sum().item()) if (refine and eng.exact) else 0,
+                     ("scan_only_no_refine" if refine else "with_fp32_refine"): round(recall_other, 6),
                      ("scan_only_max_abs_score_err" if refine else "with_fp32_refine_max_abs_score_err"): err_other}
 
     # ---- roofline of the dominant kernel (the scan), hipEvent-timed on the launch stream; the re-rank beside it
-    qa16 = ctxs[0].q_all16 if gather_q else ctxs[0].q16
+    c0 = eng.ctxs[0]
+    qa16 = c0.q_all16 if gather_q else c0.q16
     ms_total, ms_scan = nat.time_cosine_topk(qa16, slab, rows, dim, k_scan, max(10, min(args.steps, 50)),
                                              slab_type=slab_type, scales=scales)
     ms_refine = None
     if refine:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        qa32 = ctxs[0].q_all32 if gather_q else ctxs[0].q_out
         e0.record()
         for _ in range(50):
-            nat.refine_f32(qa32, shadow, rows, id_base, ctxs[0].cand_i, k, out_scores=ctxs[0].wire.scores, out_ids=ctxs[0].wire.ids)
+            # (the segment's tail as the timed path runs it: certificate + the escalation launches)
+            qa32 = c0.q_all32 if gather_q else c0.q_out
+            nat.refine_f32_cert(qa32, qa16, shadow, rows, id_base, c0.cand_i, c0.cand_s, k, view.row_err_max, slab_type, c0.exact_ws,
+                                eng.exact_cap, out_scores=c0.wire.scores, out_ids=c0.wire.ids, status=c0.status)
+            if eng.exact:
+                nat.escalate_exact(qa32, qa16, slab, shadow, rows, id_base, k, c0.wire.scores, c0.wire.ids, c0.status, c0.exact_ws,
+                                   eng.exact_cap, scales=scales)
         e1.record(); e1.synchronize()
         ms_refine = e0.elapsed_time(e1) / 50
+    # in-run figure: the search segment (scan + merge + tile refine + certificate + escalation launches) as it runs in the timed
+    # mix, event-timed on the search lane -- what a rocprof trace of this command averages to, beside the isolated kernel_ms
+    ms_search_in_run = None
+    if not multi:
+        for i in range(n_ctx):
+            load_batch(i, i)
+        ms_search_in_run = eng.measure_search_segment_ms()
     elem = 1 if slab_type == nat.SLAB_I8 else 2
     alg_bytes = rows * pd * elem + (rows * 4 if slab_type == nat.SLAB_I8 else 0) + nq_all * pd * 2 + nq_all * k_scan * 8
     achieved = alg_bytes / (ms_scan * 1e-3) / 1e9
@@ -597,8 +616,10 @@ def main():
                 "peak": mfma_peak_tf if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round(mfma_frac if mfma_bound else hbm_frac, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": nat.scan_plan_describe(nq_all, dim, k_scan, rows, slab_type),
-                "kernel_ms": round(ms_scan, 5), "scan_merge_refine_ms": round(ms_total, 5),
-                "fp32_rerank_ms": round(ms_refine, 5) if ms_refine is not None else None,
+                "kernel_ms": round(ms_scan, 5), "kernel_ms_is": "scan kernel alone, back-to-back launches, hipEvents (crs_time_cosine_topk)",
+                "scan_merge_refine_ms": round(ms_total, 5),
+                "search_segment_ms_in_run": round(ms_search_in_run, 5) if ms_search_in_run is not None else None,
+                "fp32_rerank_cert_ms": round(ms_refine, 5) if ms_refine is not None else None,
                 "fp32_shadow_bytes": int(rows * dim * 4) if refine else 0,
                 "algorithmic_bytes": int(alg_bytes), "algorithmic_flops": int(alg_flops),
                 "hbm_frac": round(hbm_frac, 4), "mfma_frac": round(mfma_frac, 4)}
@@ -611,31 +632,35 @@ def main():
                                shape.ln_eps, shape.max_seq, shape.pooling)
         sample_rows = min(rows, 200_000)
         rows_h = shadow[:sample_rows].cpu().numpy()          # the reference stores fp32 (rag/indexing.py:114-119)
-        q_h = q32.cpu().numpy()
+        q_h = q32_all[0].cpu().numpy()
+        mask_h = np.ones((qb, QUERY_TOKENS), dtype=np.int32)
         # the HIP path on the same sample prefix against the oracle (exactness of the kernels themselves)
-        cs_, ci_ = nat.cosine_topk(ctxs[0].q16, slab, sample_rows, dim, k_scan, slab_type=slab_type, scales=scales)
-        gs_, gi_ = nat.refine_f32(q32, shadow, sample_rows, 0, ci_, k)
+        q16s = nat.queries_to_f16(q32_all[0], slab_type)
+        cs_, ci_ = nat.cosine_topk(q16s, slab, sample_rows, dim, k_scan, slab_type=slab_type, scales=scales)
+        gs_, gi_ = nat.refine_f32(q32_all[0], shadow, sample_rows, 0, ci_, k)
         rs, ri = scan_ref.cosine_topk_ref(q_h, rows_h, k)
         gi_h = gi_.cpu().numpy()
         recall_oracle = float(np.mean([scan_ref.recall_at_k(gi_h[r], ri[r]) for r in range(qb)]))
         max_err = float(np.abs(gs_.cpu().numpy() - rs).max())
-        n_done, t_enc, t_scan = 0, 0.0, 0.0
-        while (t_enc + t_scan) < args.cpu_seconds:
+        n_done, t_enc, tm = 0, 0.0, {}
+        while (t_enc + tm.get("gemm", 0.0) + tm.get("select", 0.0)) < args.cpu_seconds:
             ta = time.perf_counter()
-            er.encode_ref(ids_h, mask_h, enc_w, cfg)
-            tb = time.perf_counter()
-            scan_ref.cosine_topk_ref(q_h, rows_h, k)
-            tc = time.perf_counter()
-            t_enc += tb - ta; t_scan += tc - tb
+            er.encode_ref(ids_all[0], mask_h, enc_w, cfg)
+            t_enc += time.perf_counter() - ta
+            scan_ref.cosine_topk_ref(q_h, rows_h, k, timing=tm)
             n_done += 1
-        t_cpu = t_enc + t_scan
+        t_gemm, t_sel = tm["gemm"], tm["select"]
+        t_cpu = t_enc + t_gemm + t_sel
         # queries/s over the FULL corpus: the scan part of the sample's time scales by rows/sample_rows
-        cpu_qps = qb * n_done / (t_enc + t_scan * (rows / sample_rows))
+        cpu_qps = qb * n_done / (t_enc + (t_gemm + t_sel) * (rows / sample_rows))
+        gemm_gflops = 2.0 * qb * sample_rows * dim * n_done / max(t_gemm, 1e-9) / 1e9
         cpu = {"value": round(cpu_qps, 2), "unit": "queries/s", "cores": int(torch.get_num_threads()),
                "cpu_model": cpu_model(), "kind": "port",
                "sample": f"oracle encoder_ref.encode_ref ({qb}x{QUERY_TOKENS} tokens, torch fp32) + scan_ref.cosine_topk_ref "
-                         f"(numpy fp32 sgemm + exact top-k over the fp32 rows) on {sample_rows} of {rows} rows; {n_done} passes in "
-                         f"{t_cpu:.1f}s (encoder {t_enc:.1f}s, scan {t_scan:.1f}s), scan time scaled by rows/sample",
+                         f"(numpy fp32 sgemm per 65536-row block + partition-based exact top-k) on {sample_rows} of {rows} fp32 rows; "
+                         f"{n_done} passes in {t_cpu:.1f}s, scan time scaled by rows/sample",
+               "seconds": {"encoder": round(t_enc, 3), "sgemm": round(t_gemm, 3), "selection": round(t_sel, 3)},
+               "sgemm_gflops": round(gemm_gflops, 1),
                "recall_at_10_gpu_vs_oracle_on_sample": recall_oracle, "max_abs_score_err_on_sample": max_err}
 
     if rank == 0:
@@ -648,14 +673,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "corpus_rows": corpus_rows, "rows_per_gpu": rows, "dim": dim,
                        "queries_per_batch": nq_all, "batches_per_step": n_ctx, "queries_per_step": q_per_step,
-                       "ms_per_batch": round(ms_step / n_ctx, 5), "lanes": (f"{n_enc} encoder + {n_srch} search (encoder kernels <= 48 KB of LDS)" if pipelined else "one per batch"), "top_k": k, "k_scan": k_scan,
-                       "slab": slab_kind, "refine_fp32": refine, "encoder_in_step": not args.scan_only,
+                       "distinct_queries_in_flight": q_per_step,
+                       "ms_per_batch": round(ms_step / n_ctx, 5), "lanes": eng.describe_lanes(), "top_k": k, "k_scan": k_scan,
+                       "slab": slab_kind, "refine_fp32": refine, "exact_escalation": bool(eng.exact), "encoder_in_step": not args.scan_only,
+                       "engine": "rag._engine.RetrievalEngine (the object ContextRetriever.retrieve_batch drives)",
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",
-                       "query_tokens": QUERY_TOKENS, "hip_graph": use_graph,
-                       "collectives_per_batch": n_exchanges, "dist_single_rank": bool(multi and world == 1),
+                       "query_tokens": QUERY_TOKENS, "hip_graph": eng.use_graph,
+                       "collectives_per_batch": eng.collectives_per_batch, "dist_single_rank": bool(multi and world == 1),
                        "query_encode": ("replicated" if not gather_q else ("per-rank queries (weak scaling)" if not strong else
                                         f"sharded: {q_loc} of {qb} queries per rank" + (" [single-GPU proxy: tiled instead of gathered]" if not multi else ""))),
                        "recall_at_10_vs_fp32": recall_report, "check_ok": check_ok,
+                       "row_err_max_tracked": view.row_err_max,
                        "index_build_s_per_gpu": round(t_build, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

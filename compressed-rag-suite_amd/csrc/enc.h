@@ -32,7 +32,7 @@ int gemm_stream_launch(const _Float16* a, const _Float16* w, const float* bias, 
 int gemm_panel_chunk(int k);
 int gemm_panel_splits(int k, int m);   // fp32 partial slabs a mode-3 panel launch of m rows leaves for contraction length k
 int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
-                      int mode, hipStream_t stream);
+                      int mode, int small_lds, hipStream_t stream);
 
 // enc_qkvattn.hip: QKV projection + attention of short sequences (16 / 32 / 64 tokens) in one kernel
 bool qkv_attn_supported(int hidden, int heads, int seq);

@@ -156,31 +156,32 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   if (panel_multi < 0) { const char* e = getenv("CRS_ENC_PANEL_MULTI"); panel_multi = (e && e[0] == '0') ? 0 : 1; }
   const bool single_h = T <= kPanelMaxTokens && crs::gemm_panel_chunk(H) != 0 && (crs::gemm_panel_chunk(H) == H || panel_multi);
   // short sequences in the launch-bound regime: QKV projection + attention as one kernel (enc_qkvattn.hip)
-  const bool fuse_qa = T <= kPanelMaxTokens && qa_enabled() && crs::qkv_attn_supported(H, d->heads, seq);
+  const int small = (d->flags & CRS_ENC_SMALL_LDS) ? 1 : 0;
+  const bool fuse_qa = T <= kPanelMaxTokens && !small && qa_enabled() && crs::qkv_attn_supported(H, d->heads, seq);
   for (int li = 0; li < d->layers; ++li) {
     const crs_encoder_layer& L = w->layers[li];
     if (fuse_qa) {
       CRS_TRY(crs::qkv_attn_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "qkv + attention");
     } else {
-    if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, qkv, T, 3 * H, H, 0, st), "qkv gemm");
+    if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, qkv, T, 3 * H, H, 0, small, st), "qkv gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_qkv, L.b_qkv, nullptr, qkv, T, 3 * H, H, 0, st), "qkv gemm");
     CRS_TRY(crs::attention_launch(qkv, lens_dev, ctx, batch, seq, H, d->heads, st), "attention");
     }
     if (big_ln_h) {
       CRS_TRY(crs::gemm_rowln2_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, H, x32, x16, st), "out projection + layernorm 1");
     } else if (panel_h) {
-      CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, st), "out gemm");
+      CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, small, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(H, T), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
     }
-    if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_up, L.b_up, ffn, T, F, H, 1, st), "ffn up gemm");
+    if (single_h) CRS_TRY(crs::gemm_panel_launch(x16, (const _Float16*)L.w_up, L.b_up, ffn, T, F, H, 1, small, st), "ffn up gemm");
     else CRS_TRY(crs::gemm_f16_launch(x16, (const _Float16*)L.w_up, L.b_up, nullptr, ffn, T, F, H, 1, st), "ffn up gemm");
     if (big_ln_f) {
       CRS_TRY(crs::gemm_rowln2_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, F, x32, x16, st), "ffn down projection + layernorm 2");
     } else if (panel_f) {
-      CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, st), "ffn down gemm");
+      CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, small, st), "ffn down gemm");
       CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(F, T), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, y32, T, H, F, 2, st), "ffn down gemm");

@@ -326,11 +326,13 @@ __global__ __launch_bounds__(kPanelThreads, 1) void gemm_panel_kernel(const _Flo
 
 template <int MODE, int TM>
 int launch_panel_t(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
-                   int splitk, int kin_req, hipStream_t stream) {
+                   int splitk, int kin_req, int small_lds, hipStream_t stream) {
   static bool attr_done = false;
-  // CRS_PANEL_KC=128|256: stage the K range in chunks of that many columns (see the kernel: small-LDS form)
-  static int kc_cap = -1;
-  if (kc_cap < 0) { const char* e = getenv("CRS_PANEL_KC"); kc_cap = e ? atoi(e) : 0; if (kc_cap != 128 && kc_cap != 256 && kc_cap != 384) kc_cap = 0; }
+  // small_lds (crs_encoder_desc.flags & CRS_ENC_SMALL_LDS): stage the K range in 128-column chunks (<= 48 KB of LDS: the
+  // forward can then run beside a scan's resident workgroups).  CRS_PANEL_KC=128|256|384 forces a chunk size (A/B runs).
+  static int kc_env = -1;
+  if (kc_env < 0) { const char* e = getenv("CRS_PANEL_KC"); kc_env = e ? atoi(e) : 0; if (kc_env != 128 && kc_env != 256 && kc_env != 384) kc_env = 0; }
+  const int kc_cap = kc_env ? kc_env : (small_lds ? 128 : 0);
   // A launch of more workgroups than CUs stages 128 columns at a time: 48 KB of LDS, up to three workgroups resident
   // per CU, one workgroup's transfers under another's MFMAs (bge-base at query-batch sizes: QKV 288, FFN-up 384, FFN-down
   // 768 workgroups).  Measured on the bge-base query chain (tools/enc_chain_profile.py): 64 x 16 tokens 945 -> ~800 us per
@@ -356,11 +358,11 @@ int launch_panel_t(const _Float16* a, const _Float16* w, const float* bias, void
 // 128-row tiles once 64-row tiles would need more than one wave of workgroups on the chip
 template <int MODE>
 int launch_panel(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k, int kc,
-                 int splitk, int kin, hipStream_t stream) {
+                 int splitk, int kin, int small_lds, hipStream_t stream) {
   const long wgs64 = (long)((n + PN - 1) / PN) * ((m + 63) / 64) * splitk;
   // (forcing 64- or 128-row tiles everywhere measured within 2 % either way on both models' query chains)
-  if (wgs64 > 256 && m > 64) return launch_panel_t<MODE, 128>(a, w, bias, out, m, n, k, kc, splitk, kin, stream);
-  return launch_panel_t<MODE, 64>(a, w, bias, out, m, n, k, kc, splitk, kin, stream);
+  if (wgs64 > 256 && m > 64) return launch_panel_t<MODE, 128>(a, w, bias, out, m, n, k, kc, splitk, kin, small_lds, stream);
+  return launch_panel_t<MODE, 64>(a, w, bias, out, m, n, k, kc, splitk, kin, small_lds, stream);
 }
 
 }  // namespace
@@ -418,16 +420,16 @@ int gemm_panel_splits(int k, int m) {
 // out: mode 0/1 fp16 [M,N] (any k that is a multiple of the chunk: the workgroup walks the chunks); mode 3 fp32
 // [gemm_panel_splits(k, m)][M][N] partials
 int gemm_panel_launch(const _Float16* a, const _Float16* w, const float* bias, void* out, int m, int n, int k,
-                      int mode, hipStream_t stream) {
+                      int mode, int small_lds, hipStream_t stream) {
   const int kc = gemm_panel_chunk(k);
   if (kc == 0) return -1;
   const int chunks = k / kc;
   switch (mode) {
-    case 0: return launch_panel<0>(a, w, bias, out, m, n, k, kc, 1, chunks, stream);
-    case 1: return launch_panel<1>(a, w, bias, out, m, n, k, kc, 1, chunks, stream);
+    case 0: return launch_panel<0>(a, w, bias, out, m, n, k, kc, 1, chunks, small_lds, stream);
+    case 1: return launch_panel<1>(a, w, bias, out, m, n, k, kc, 1, chunks, small_lds, stream);
     case 3: {
       const int splitk = gemm_panel_splits(k, m);
-      return launch_panel<3>(a, w, bias, out, m, n, k, kc, splitk, chunks / splitk, stream);
+      return launch_panel<3>(a, w, bias, out, m, n, k, kc, splitk, chunks / splitk, small_lds, stream);
     }
     default: return -1;
   }

@@ -251,16 +251,16 @@ void merge_topk_wire_out(const Tensor& wire, int64_t nlists, int64_t nq, int64_t
 }
 
 // ---- encoder -------------------------------------------------------------------------------------------------
-// desc = [vocab_size, hidden, layers, heads, ffn, max_pos, pooling]; weights = [word_emb, pos_emb, type_emb, emb_ln_g, emb_ln_b]
+// desc = [vocab_size, hidden, layers, heads, ffn, max_pos, pooling, flags (CRS_ENC_*, optional)]; weights = [word_emb, pos_emb, type_emb, emb_ln_g, emb_ln_b]
 // followed by 12 tensors per layer in crs_encoder_layer order (w_qkv b_qkv w_o b_o ln1_g ln1_b w_up b_up w_down b_down ln2_g ln2_b).
 void encoder_forward(const Tensor& ids, const Tensor& lens, at::TensorList weights, at::IntArrayRef desc, double ln_eps, Tensor workspace,
                      Tensor out, c10::optional<Tensor> q16_out, int64_t slab_type, bool normalize, c10::optional<Tensor> hidden_out) {
   want(ids, at::kInt, "ids");
   want(lens, at::kInt, "lens");
   want(out, at::kFloat, "out");
-  TORCH_CHECK(desc.size() == 7, "desc = [vocab_size, hidden, layers, heads, ffn, max_pos, pooling]");
+  TORCH_CHECK(desc.size() == 7 || desc.size() == 8, "desc = [vocab_size, hidden, layers, heads, ffn, max_pos, pooling(, flags)]");
   crs_encoder_desc d{(int32_t)desc[0], (int32_t)desc[1], (int32_t)desc[2], (int32_t)desc[3], (int32_t)desc[4], (int32_t)desc[5],
-                     (float)ln_eps, (int32_t)desc[6]};
+                     (float)ln_eps, (int32_t)desc[6], desc.size() == 8 ? (int32_t)desc[7] : 0};
   TORCH_CHECK((int64_t)weights.size() == 5 + 12 * (int64_t)d.layers, "weights must hold 5 + 12 * layers tensors");
   TORCH_CHECK(ids.dim() == 2 && lens.numel() == ids.size(0) && out.numel() == ids.size(0) * d.hidden, "ids [B, S], lens [B], out [B, H]");
   for (const Tensor& t : weights) TORCH_CHECK(t.is_cuda() && t.is_contiguous() && t.device() == ids.device(), "weights must be contiguous tensors on the device of ids");

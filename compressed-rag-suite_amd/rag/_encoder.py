@@ -16,11 +16,12 @@ import numpy as np
 from rag import _native as nat
 
 POOL_MEAN, POOL_CLS = 0, 1
+ENC_SMALL_LDS = 1      # CRS_ENC_SMALL_LDS: kernel forms of <= 48 KB of LDS (forwards that run beside a scan)
 
 
 class EncoderDesc(Structure):
     _fields_ = [("vocab_size", c_int32), ("hidden", c_int32), ("layers", c_int32), ("heads", c_int32),
-                ("ffn", c_int32), ("max_pos", c_int32), ("ln_eps", c_float), ("pooling", c_int32)]
+                ("ffn", c_int32), ("max_pos", c_int32), ("ln_eps", c_float), ("pooling", c_int32), ("flags", c_int32)]
 
 
 class EncoderLayer(Structure):
@@ -94,7 +95,7 @@ class HipEncoder:
             return t
 
         self.desc = EncoderDesc(shape.vocab_size, shape.hidden, shape.layers, shape.heads, shape.ffn, shape.max_pos,
-                                shape.ln_eps, POOL_CLS if shape.pooling == "cls" else POOL_MEAN)
+                                shape.ln_eps, POOL_CLS if shape.pooling == "cls" else POOL_MEAN, 0)
         self._layers = (EncoderLayer * shape.layers)()
         for i in range(shape.layers):
             p = f"encoder.layer.{i}."
@@ -126,7 +127,7 @@ class HipEncoder:
         """crs_encoder_desc as the int list torch.ops.crs.encoder_forward takes (read from `desc`, so tests that
         switch `desc.pooling` are honoured)."""
         d = self.desc
-        return [d.vocab_size, d.hidden, d.layers, d.heads, d.ffn, d.max_pos, d.pooling]
+        return [d.vocab_size, d.hidden, d.layers, d.heads, d.ffn, d.max_pos, d.pooling, d.flags]
 
     def workspace_bytes(self, batch: int, seq: int) -> int:
         out = c_size_t(0)
@@ -134,7 +135,7 @@ class HipEncoder:
         return int(out.value)
 
     def forward(self, ids, lens, normalize: bool = True, return_hidden: bool = False, out=None, workspace=None,
-                q16_out=None, slab_type: int = nat.SLAB_F16):
+                q16_out=None, slab_type: int = nat.SLAB_F16, small_lds: bool = False):
         """ids: int32 [B, S] (numpy or cuda tensor, right padded), lens: int32 [B].
         Returns cuda fp32 [B, H] (and [B, S, H] hidden states when return_hidden).  With `q16_out`
         (cuda fp16 [B, padded_dim]) the pooled, normalised embeddings are also written there in the scan's
@@ -163,7 +164,10 @@ class HipEncoder:
             if tuple(q16_out.shape) != (b, nat.padded_dim(self.shape.hidden, slab_type)) or q16_out.dtype != torch.float16:
                 raise ValueError("q16_out must be fp16 [batch, padded_dim]")
         hidden = torch.empty((b, s, self.shape.hidden), dtype=torch.float32, device=self.device) if return_hidden else None
+        desc = self._desc_list
+        if small_lds:          # per call, not process-wide: the role-lane engine asks for it, everyone else gets the default forms
+            desc = desc[:7] + [desc[7] | ENC_SMALL_LDS]
         with nat._translate():
-            nat.ops().encoder_forward(ids, lens, self._wlist, self._desc_list, float(self.desc.ln_eps), ws, out, q16_out,
+            nat.ops().encoder_forward(ids, lens, self._wlist, desc, float(self.desc.ln_eps), ws, out, q16_out,
                                       int(slab_type), bool(normalize), hidden)
         return (out, hidden) if return_hidden else out

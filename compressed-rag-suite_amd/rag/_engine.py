@@ -1,0 +1,323 @@
+"""Throughput engine of the retrieve path: S query batches in flight over ROLE lanes, each batch replayed from hipGraphs.
+
+What ``ContextRetriever.retrieve_batch`` (large batches) and ``bench.py`` run -- one object, so that the rate bench.py reports
+is the rate the plugin surface reaches.  The reference times one query at a time in a Python loop
+(/root/reference/evaluation/retrieval/benchmark.py:241-247); it has no batched entry point, so this layer is new.
+
+One BATCH of Qb queries = device segments with the (optional) collectives between them:
+    E  encode   token ids [Qb, S] -> fp32 unit embeddings + the scan's fp16 query block        (crs::encoder_forward)
+    S  search   exact scan of this rank's shard, over-fetching k' candidates                   (crs::cosine_topk)
+                -> fp32 re-rank against the shadow + per-query exactness certificate            (crs::refine_f32_cert)
+                -> escalation of unproven queries, a no-op launch when all are proven           (crs::escalate_exact)
+                -> best k in this rank's wire block
+    M  merge    (N > 1) after ONE all-gather of the wire blocks: k-way merge                    (crs::merge_topk_wire)
+Every segment reads and writes fixed buffers of its buffer set (``_Ctx``), so it is captured once and replayed.
+
+Lanes.  The GPU runs a process's streams on four hardware queues; a query-encoder forward is a chain of ~40 dependent launches
+of a few microseconds each (latency, not work), a scan is one kernel that wants every byte of HBM bandwidth, and an encoder
+kernel with > 48 KB of LDS cannot start on a CU that holds two scan workgroups.  ``lanes='split'`` gives the streams ROLES --
+encoder forwards of upcoming batches on encoder lanes, searches on a search lane, tied by events per buffer set -- and asks the
+encoder for its <= 48 KB kernel forms (``CRS_ENC_SMALL_LDS`` in the descriptor's flags: per call, not process-wide).
+``'batch'`` keeps every batch wholly on its own stream.  ``'auto'`` splits for MiniLM-class encoders (hidden <= 384) over scans
+of >= 512 MB per batch, where it measured faster, and keeps one lane per batch otherwise.
+"""
+from __future__ import annotations
+
+import sys
+from dataclasses import dataclass
+from typing import List, Optional
+
+from rag import _native as nat
+
+
+@dataclass
+class ShardView:
+    """The rows of ONE device that an engine searches (tensors stay owned by the store / the caller)."""
+    slab: object                 # cuda fp16 | int8 [>= n, pdim]
+    scales: object               # cuda fp32 [>= n] (int8) or None
+    shadow: object               # cuda fp32 [>= n, dim] or None (no fp32 re-rank then)
+    n: int
+    dim: int
+    slab_type: int
+    id_base: int = 0             # added to local rows: the shard's first global row
+    row_err_max: float = -1.0    # tracked |stored row - fp32 row|_2 maximum (< 0: the analytic worst case)
+
+
+class _Ctx:
+    """Buffers of one in-flight query batch (a batch touches nothing outside its _Ctx + read-only state)."""
+
+
+class RetrievalEngine:
+    def __init__(self, encoder, view: ShardView, queries_per_batch: int, seq: int, top_k: int, *, k_scan: int = 32,
+                 refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 8, lanes: str = "auto",
+                 enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
+                 queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True):
+        """queries_per_batch: the GLOBAL batch every rank searches (strong scaling), or with ``queries_per_rank`` the queries
+        THIS rank contributes (weak scaling: the scan then sees world x that many).  encode_shard = W > 1: each rank encodes
+        Qb / W queries and the embeddings are all-gathered first (two collectives per batch instead of one).
+        proxy_encode_shard (diagnostic, one rank): encode Qb / W queries and tile them in place of that all-gather.
+        encode=False (diagnostic): the caller fills ``ctx.q_out`` / uses set_queries(); no encoder in the batch."""
+        import torch
+        nat.require_gpu()
+        self.torch = torch
+        self.enc, self.view = encoder, view
+        self.dev = view.slab.device
+        self.dist, self.world, self.rank = dist, world, rank
+        self.multi = dist is not None
+        self.k, self.seq = int(top_k), int(seq)
+        self.refine = bool(refine) and view.shadow is not None
+        self.k_scan = min(nat.MAX_K, max(self.k, int(k_scan))) if self.refine else self.k
+        self.exact = (view.slab_type == nat.SLAB_F16) if exact == "auto" else bool(exact)
+        self.exact = self.exact and self.refine
+        self.exact_cap = int(exact_cap)
+        self.encode = bool(encode)
+        qb = int(queries_per_batch)
+        self.nq_all = qb * world if queries_per_rank else qb
+        shard_w = 1
+        if self.multi and not queries_per_rank and encode_shard > 1 and qb % encode_shard == 0:
+            shard_w = encode_shard
+        if not self.multi and proxy_encode_shard > 1 and qb % proxy_encode_shard == 0:
+            shard_w = proxy_encode_shard
+        self.shard_w = shard_w
+        self.q_loc = qb // shard_w                          # queries THIS rank encodes per batch
+        self.enc_lo = (rank if self.multi else 0) * self.q_loc if shard_w > 1 else 0
+        self.gather_q = (self.multi and (queries_per_rank or shard_w > 1)) or (not self.multi and shard_w > 1)
+        self.pd = nat.padded_dim(view.dim, view.slab_type)
+        scan_bytes = view.n * self.pd * (1 if view.slab_type == nat.SLAB_I8 else 2)
+        hidden = encoder.shape.hidden if encoder is not None else view.dim
+        self.pipelined = lanes == "split" or (lanes == "auto" and self.encode and hidden <= 384 and scan_bytes >= (512 << 20))
+        self.n_ctx = max(1, int(n_ctx))
+        self.use_graph = bool(graphs)
+        if self.pipelined:
+            # two encoder lanes feed ONE search lane at every shard size (one encoder lane starves scans of <= 2.5 M rows); a
+            # second search lane would overlap consecutive scans (1 - 2 % on 10 M rows) and make per-kernel durations meaningless
+            self.n_enc = enc_lanes if enc_lanes > 0 else 2
+            self.n_srch = search_lanes if search_lanes > 0 else 1
+            self.enc_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_enc)]
+            self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_srch)]
+        else:
+            self.n_enc = self.n_srch = self.n_ctx
+            self.enc_streams = self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_ctx)]
+        self.ctxs: List[_Ctx] = [self._make_ctx() for _ in range(self.n_ctx)]
+        # segments of a batch, in order; the lane each runs on; the collective that follows it (N > 1)
+        self.segs = [self._seg_encode, self._seg_search] + ([self._seg_merge] if self.multi else [])
+        self.seg_lanes = ["E", "S", "S"][: len(self.segs)]
+        self.exchanges = [None] * len(self.segs)
+        if self.multi and self.gather_q:   # queries encoded in shards (or per-rank queries): embeddings gathered first
+            self.exchanges[0] = lambda c: dist.all_gather_into_tensor(c.q_all32, c.q_out)
+        if self.multi:                     # THE exchange of a sharded search: every rank's wire block
+            self.exchanges[1] = lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)
+        self.collectives_per_batch = sum(1 for e in self.exchanges if e is not None)
+        self._issued = 0
+        self._warm = False
+
+    # ---- buffers ---------------------------------------------------------------------------------------------------
+    def _make_ctx(self) -> _Ctx:
+        torch, v, dev = self.torch, self.view, self.dev
+        c = _Ctx()
+        c.ids = torch.zeros((self.q_loc, self.seq), dtype=torch.int32, device=dev)
+        c.lens = torch.ones(self.q_loc, dtype=torch.int32, device=dev)
+        c.q_out = torch.empty((self.q_loc, v.dim), dtype=torch.float32, device=dev)
+        c.q16 = torch.empty((self.q_loc, self.pd), dtype=torch.float16, device=dev)
+        c.enc_ws = (torch.empty(self.enc.workspace_bytes(self.q_loc, self.seq), dtype=torch.uint8, device=dev)
+                    if self.encode else None)
+        c.ws = torch.empty(nat.scan_workspace_bytes(self.nq_all, v.dim, self.k_scan, v.n), dtype=torch.uint8, device=dev)
+        c.cand_s = torch.empty((self.nq_all, self.k_scan), dtype=torch.float32, device=dev)
+        c.cand_i = torch.empty((self.nq_all, self.k_scan), dtype=torch.int64, device=dev)
+        c.wire = nat.WireBlock(self.nq_all, self.k, dev, self.world, gather=self.multi)   # this rank's (ids | scores) block
+        c.status = torch.zeros(self.nq_all, dtype=torch.int32, device=dev)
+        c.exact_ws = (torch.empty(nat.exact_workspace_bytes(self.nq_all, self.exact_cap), dtype=torch.uint8, device=dev)
+                      if self.refine else None)
+        c.graphs = None
+        if self.multi:
+            c.fin_s = torch.empty((self.nq_all, self.k), dtype=torch.float32, device=dev)
+            c.fin_i = torch.empty((self.nq_all, self.k), dtype=torch.int64, device=dev)
+        if self.gather_q:
+            c.q_all32 = torch.empty((self.nq_all, v.dim), dtype=torch.float32, device=dev)
+            c.q_all16 = torch.empty((self.nq_all, self.pd), dtype=torch.float16, device=dev)
+        c.ev_enc, c.ev_done = torch.cuda.Event(), torch.cuda.Event()
+        return c
+
+    def set_tokens(self, ctx_index: int, ids, lens, stream=None) -> None:
+        """Token ids / lengths of the NEXT batch of buffer set ctx_index (this rank's slice when the encode is sharded):
+        int32 [q_loc, seq] / [q_loc], host or device.  Queued behind the previous batch of that buffer set."""
+        torch, c = self.torch, self.ctxs[ctx_index]
+        st = stream or self.enc_streams[ctx_index % self.n_enc]
+        with torch.cuda.stream(st):
+            st.wait_event(c.ev_done)
+            c.ids.copy_(torch.as_tensor(ids, dtype=torch.int32), non_blocking=True)
+            c.lens.copy_(torch.as_tensor(lens, dtype=torch.int32), non_blocking=True)
+            c.ev_done.record(st)
+
+    # ---- segments --------------------------------------------------------------------------------------------------
+    def _seg_encode(self, c: _Ctx) -> None:      # token ids -> fp32 embeddings + the scan's fp16 query block
+        if self.encode:
+            self.enc.forward(c.ids, c.lens, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=self.view.slab_type,
+                             small_lds=self.pipelined)
+        else:
+            nat.queries_to_f16(c.q_out, self.view.slab_type, out=c.q16)
+
+    def _seg_search(self, c: _Ctx, refine: Optional[bool] = None) -> None:   # all queries x this rank's shard -> wire block
+        v = self.view
+        refine = self.refine if refine is None else refine
+        qa32 = c.q_all32 if self.gather_q else c.q_out
+        if self.gather_q:
+            if not self.multi:     # proxy: the local queries tiled in place of the all-gather
+                c.q_all32.view(self.shard_w, self.q_loc, v.dim).copy_(c.q_out.unsqueeze(0).expand(self.shard_w, self.q_loc, v.dim))
+            nat.queries_to_f16(qa32, v.slab_type, out=c.q_all16)
+        qa16 = c.q_all16 if self.gather_q else c.q16
+        if refine:
+            nat.cosine_topk(qa16, v.slab, v.n, v.dim, self.k_scan, slab_type=v.slab_type, scales=v.scales, id_base=v.id_base,
+                            workspace=c.ws, out_scores=c.cand_s, out_ids=c.cand_i)
+            nat.refine_f32_cert(qa32, qa16, v.shadow, v.n, v.id_base, c.cand_i, c.cand_s, self.k, v.row_err_max, v.slab_type,
+                                c.exact_ws, self.exact_cap, out_scores=c.wire.scores, out_ids=c.wire.ids, status=c.status)
+            if self.exact:
+                nat.escalate_exact(qa32, qa16, v.slab, v.shadow, v.n, v.id_base, self.k, c.wire.scores, c.wire.ids, c.status,
+                                   c.exact_ws, self.exact_cap, scales=v.scales)
+        else:
+            nat.cosine_topk(qa16, v.slab, v.n, v.dim, self.k, slab_type=v.slab_type, scales=v.scales, id_base=v.id_base,
+                            workspace=c.ws, out_scores=c.wire.scores, out_ids=c.wire.ids)
+
+    def _seg_merge(self, c: _Ctx) -> None:       # N > 1: the gathered wire blocks -> global top-k
+        nat.merge_topk_wire(c.wire.gathered, self.world, self.nq_all, self.k, self.k, out_scores=c.fin_s, out_ids=c.fin_i)
+
+    # ---- issue -----------------------------------------------------------------------------------------------------
+    def submit(self, ctx_index: int):
+        """Issue one batch from buffer set ctx_index: encode on an encoder lane, search (+ exchange + merge) on a search lane.
+        Returns the (scores, ids) DEVICE tensors the batch will fill (valid after ``wait(ctx_index)``)."""
+        torch, c = self.torch, self.ctxs[ctx_index]
+        b = self._issued
+        self._issued += 1
+        lane = {"E": self.enc_streams[b % self.n_enc], "S": self.srch_streams[b % self.n_srch]}
+        prev = None
+        for j, seg in enumerate(self.segs):
+            st = lane[self.seg_lanes[j]]
+            with torch.cuda.stream(st):
+                if j == 0:
+                    st.wait_event(c.ev_done)          # the previous user of this buffer set is through (no-op before its first use)
+                elif st is not prev:
+                    st.wait_event(c.ev_enc)           # lane change: the encoder lane's output (and its collective) is complete
+                if c.graphs is not None:
+                    c.graphs[j].replay()
+                else:
+                    seg(c)
+                if self.exchanges[j] is not None:
+                    self.exchanges[j](c)
+                if j == 0:
+                    c.ev_enc.record(st)
+                if j == len(self.segs) - 1:
+                    c.ev_done.record(st)
+            prev = st
+        return (c.fin_s, c.fin_i) if self.multi else (c.wire.scores, c.wire.ids)
+
+    def wait(self, ctx_index: int) -> None:
+        self.ctxs[ctx_index].ev_done.synchronize()
+
+    def outputs(self, ctx_index: int):
+        c = self.ctxs[ctx_index]
+        return ((c.fin_s, c.fin_i) if self.multi else (c.wire.scores, c.wire.ids)) + (c.status,)
+
+    def warm_up(self) -> None:
+        """Two eager batches per buffer set, then capture every segment into a hipGraph (run eagerly if a capture fails)."""
+        if self._warm:
+            return
+        torch = self.torch
+        torch.cuda.synchronize()
+        for i, c in enumerate(self.ctxs):
+            for _ in range(2):
+                self.submit(i)
+            torch.cuda.synchronize()
+            if self.use_graph:
+                # thread_local: with N > 1 the process group's watchdog thread polls events while we capture
+                try:
+                    gl = []
+                    for j, seg in enumerate(self.segs):
+                        st = (self.enc_streams if self.seg_lanes[j] == "E" else self.srch_streams)[0]
+                        g_ = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
+                            seg(c)
+                        gl.append(g_)
+                    c.graphs = gl
+                except Exception as exc:   # noqa: BLE001 -- report and keep going without graphs
+                    print(f"[engine] hipGraph capture failed on rank {self.rank} ({exc!r}); launching eagerly", file=sys.stderr, flush=True)
+                    self.use_graph = False
+                    for cc in self.ctxs:
+                        cc.graphs = None
+                    torch.cuda.synchronize()   # (no break: every rank must still run the same warm-up collectives)
+        self._warm = True
+
+    def step(self) -> None:
+        """One batch from every buffer set (the unit bench.py times)."""
+        for i in range(self.n_ctx):
+            self.submit(i)
+
+    def measure_search_segment_ms(self, rounds: int = 2):
+        """Mean duration of the SEARCH segment (scan + merge + tile refine + certificate + escalation launches) while the
+        engine runs its normal mix, hipEvent-timed on the search lane over `rounds` steps (the first is discarded).
+        Single rank only; None without graphs."""
+        torch = self.torch
+        if self.multi or not self._warm or self.ctxs[0].graphs is None:
+            return None
+        torch.cuda.synchronize()
+        evs = []
+        for r in range(max(2, rounds)):
+            for c in self.ctxs:
+                b = self._issued
+                self._issued += 1
+                st_e, st_s = self.enc_streams[b % self.n_enc], self.srch_streams[b % self.n_srch]
+                with torch.cuda.stream(st_e):
+                    st_e.wait_event(c.ev_done)
+                    c.graphs[0].replay()
+                    c.ev_enc.record(st_e)
+                with torch.cuda.stream(st_s):
+                    st_s.wait_event(c.ev_enc)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st_s)
+                    c.graphs[1].replay()
+                    e1.record(st_s)
+                    c.ev_done.record(st_s)
+                if r:
+                    evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+
+    def describe_lanes(self) -> str:
+        return (f"{self.n_enc} encoder + {self.n_srch} search (encoder kernels <= 48 KB of LDS)" if self.pipelined else "one per batch")
+
+    # ---- the product entry: many query batches through the pipeline -------------------------------------------------
+    def search_token_batches(self, batches):
+        """batches: iterable of (ids int32 [m, seq], lens int32 [m]) host arrays with m <= queries per batch (a short last
+        batch is padded with copies of its first query).  Yields, in order, (scores [m, k], rows [m, k], status [m]) numpy
+        arrays.  Up to n_ctx batches are in flight; results are read back as their buffer set comes round again."""
+        import numpy as np
+        if self.multi or self.gather_q:
+            raise nat.NativeError("search_token_batches drives a single-rank engine")
+        self.warm_up()
+        pending = {}          # ctx index -> rows of that batch that are real
+        order = []
+
+        def collect(i):
+            self.wait(i)
+            s, r, st = self.outputs(i)
+            m = pending.pop(i)
+            return s[:m].cpu().numpy(), r[:m].cpu().numpy(), st[:m].cpu().numpy()
+
+        nb = 0
+        for ids, lens in batches:
+            i = nb % self.n_ctx
+            if i in pending:
+                order.remove(i)
+                yield collect(i)
+            ids = np.asarray(ids, dtype=np.int32)
+            lens = np.asarray(lens, dtype=np.int32)
+            m = ids.shape[0]
+            if m < self.q_loc:
+                ids = np.concatenate([ids, np.repeat(ids[:1], self.q_loc - m, axis=0)])
+                lens = np.concatenate([lens, np.repeat(lens[:1], self.q_loc - m)])
+            self.set_tokens(i, ids, lens)
+            self.submit(i)
+            pending[i] = m
+            order.append(i)
+            nb += 1
+        for i in list(order):
+            yield collect(i)

@@ -574,6 +574,38 @@ class VectorStore:
             logger.error(f"Search failed: {e}")
             raise
 
+    def engine_view(self):
+        """This store as ONE device shard for rag._engine.RetrievalEngine, or None when its layout needs the general path
+        (several devices, SPMD sharding, a non-identity row map)."""
+        col = self.collection
+        if col is None or len(col.shards) != 1 or self.sharded or col.n == 0:
+            return None
+        sh = col.shards[0]
+        if not sh.identity:
+            return None
+        from rag._engine import ShardView
+        return ShardView(sh.slab, sh.scales, sh.shadow if sh.refine_fp32 else None, sh.n, sh.dim, sh.slab_type, 0, sh.row_err_max())
+
+    def search_rows(self, query_embeddings, top_k: int):
+        """search_batch without the sidecar lookup: (scores fp32 [nq, k], sidecar rows int64 [nq, k]) as numpy, best first,
+        -1 rows = fewer than k hits.  (retrieve_batch builds its dicts straight from these.)"""
+        import torch
+        if self.collection is None:
+            raise ValueError("No collection available. Create index first.")
+        col = self.collection
+        nq = len(query_embeddings)
+        if col.count() == 0 or nq == 0:
+            return np.zeros((nq, 0), dtype=np.float32), np.zeros((nq, 0), dtype=np.int64)
+        top_k = min(top_k, col.count())
+        if isinstance(query_embeddings, torch.Tensor):
+            q32 = query_embeddings.to(device=col.device, dtype=torch.float32).contiguous()
+        else:
+            q32 = torch.from_numpy(np.ascontiguousarray(query_embeddings, dtype=np.float32)).to(col.device)
+        if q32.shape[1] != col.dim:
+            raise ValueError(f"Query dimension {q32.shape[1]} doesn't match the index dimension {col.dim}")
+        scores, rows = self._topk_device(q32, top_k, None)
+        return scores.cpu().numpy(), rows.cpu().numpy()
+
     def search_batch(self, query_embeddings, top_k: int = 5, where: Optional[dict] = None,
                      where_document: Optional[dict] = None) -> Dict[str, Any]:
         """Many queries per launch: query_embeddings fp32 [nq, d] (numpy or cuda tensor).
@@ -597,13 +629,15 @@ class VectorStore:
             return {k: [[] for _ in range(nq)] for k in _EMPTY}
         scores, rows = self._topk_device(q32, top_k, allowed)
         sh, rh = scores.cpu().numpy(), rows.cpu().numpy()
+        dist = (np.float32(1.0) - sh).astype(np.float64)          # one vectorised pass; float(np.float32) per hit was the cost
+        ids_l, docs_l, metas_l = col.ids, col.documents, col.metadatas
         out = {'ids': [], 'documents': [], 'metadatas': [], 'distances': []}
         for a in range(nq):
-            valid = [b for b in range(top_k) if rh[a, b] >= 0]
-            out['ids'].append([col.ids[rh[a, b]] for b in valid])
-            out['documents'].append([col.documents[rh[a, b]] for b in valid])
-            out['metadatas'].append([col.metadatas[rh[a, b]] for b in valid])
-            out['distances'].append([float(np.float32(1.0) - sh[a, b]) for b in valid])
+            valid = [r for r in rh[a].tolist() if r >= 0]
+            out['ids'].append([ids_l[r] for r in valid])
+            out['documents'].append([docs_l[r] for r in valid])
+            out['metadatas'].append([metas_l[r] for r in valid])
+            out['distances'].append(dist[a, : len(valid)].tolist())
         return out
 
     # -- management ----------------------------------------------------------------------------

@@ -34,6 +34,8 @@ class ContextRetriever:
         self.similarity_threshold = config.get('similarity_threshold', 0.0)
         self.rerank = config.get('rerank', False)
         self.diversity_penalty = config.get('diversity_penalty', 0.0)
+        self.batch_queries = int(config.get('batch_queries', 64))    # additive: queries per launch of retrieve_batch's engine
+        self._engine, self._engine_key = None, None
         self.distance_metric = self._get_distance_metric()
         logger.info(f"Using distance metric: {self.distance_metric}")
 
@@ -110,23 +112,128 @@ class ContextRetriever:
             logger.error(f"Retrieval failed: {e}")
             raise
 
+    # ---- batched retrieval (additive; the reference has no batched entry point) --------------------------------------
+    def _engine_for(self, fetch: int, seq: int):
+        """The throughput engine (rag/_engine.py: role lanes, hipGraph replay, several batches in flight) for this store /
+        encoder pair, or None when the store's layout needs the general path (several shards, filters, top_k > 64)."""
+        store, model = self.vector_store, self.embedding_model
+        view = store.engine_view() if hasattr(store, "engine_view") else None
+        enc = getattr(model, "model", None)
+        if view is None or enc is None or fetch > 64 or not getattr(model, "normalize", True):
+            return None
+        key = (fetch, seq, view.n, int(view.slab.data_ptr()), self.batch_queries)
+        if self._engine_key != key:
+            from rag._engine import RetrievalEngine
+            self._engine = RetrievalEngine(enc, view, self.batch_queries, seq, fetch, k_scan=store.refine_overfetch,
+                                           refine=view.shadow is not None, exact=store.refine_exact, exact_cap=store.exact_cap)
+            self._engine_key = key
+        return self._engine
+
+    def _search_many(self, queries: List[str], fetch: int):
+        """-> per query (scores fp32 [<= fetch], sidecar rows int64 [<= fetch]) numpy arrays, best first."""
+        import numpy as _np
+        model, store = self.embedding_model, self.vector_store
+        qb = self.batch_queries
+        eng = None
+        if len(queries) >= qb and hasattr(store, 'engine_view') and store.collection is not None and store.collection.count() > 0:
+            token_ids = model.tokenize(list(queries))
+            longest = max(len(t) for t in token_ids)
+            seq = next((st for st in (16, 32, 64) if longest <= st and st <= model.shape.max_seq), None)
+            eng = self._engine_for(min(fetch, store.collection.count()), seq) if seq else None
+        if eng is None:                       # general path: one encoder pass + one search launch for the whole list
+            emb = model.embed_device(list(queries)) if hasattr(model, "embed_device") else model.embed(list(queries))
+            if not hasattr(store, "search_rows"):          # any store with the additive search_batch (duck-typed)
+                return store.search_batch(emb, top_k=fetch)
+            scores, rows = store.search_rows(emb, fetch)
+            return [(scores[i], rows[i]) for i in range(len(queries))]
+        pad = getattr(model.tokenizer, "pad_id", 0)
+
+        def batches():
+            for lo in range(0, len(token_ids), qb):
+                ids = _np.full((min(qb, len(token_ids) - lo), eng.seq), pad, dtype=_np.int32)
+                lens = _np.empty(ids.shape[0], dtype=_np.int32)
+                for r, t in enumerate(token_ids[lo:lo + qb]):
+                    ids[r, :len(t)] = t
+                    lens[r] = len(t)
+                yield ids, lens
+
+        out, tally = [], {"queries": len(queries), "certified": 0, "escalated": 0, "unproven": 0}
+        for s, r, st in eng.search_token_batches(batches()):
+            out.extend((s[i], r[i]) for i in range(s.shape[0]))
+            tally["certified"] += int((st == 0).sum())
+            tally["escalated"] += int((st == 1).sum()) if eng.exact else 0
+            tally["unproven"] += int((st == 2).sum()) + (0 if eng.exact else int((st == 1).sum()))
+        if eng.refine:
+            store.last_exactness = tally
+        return out
+
     def retrieve_batch(self, queries: List[str], top_k: Optional[int] = None) -> List[List[Dict]]:
-        """``[retrieve(q) for q in queries]`` with one encoder pass and one scan launch for the
-        whole batch (requires the store's additive ``search_batch``)."""
+        """``[retrieve(q) for q in queries]`` for many queries at once: the encoder forwards and scans of the whole list
+        run through the throughput engine (Qb = ``batch_queries`` per launch, several launches in flight), scoring and the
+        threshold are vectorised (same fp64 arithmetic as ``_distance_to_similarity``), and the MMR step re-embeds the chunk
+        texts of ALL queries in one encoder pass (the reference re-embeds per query, rag/retrieval.py:238-239).
+        Same dicts, same order as ``retrieve`` up to the rounding of batched encoder forwards."""
         k = top_k or self.top_k
         if not queries:
             return []
-        embeddings = self.embedding_model.embed(list(queries))
-        results = self.vector_store.search_batch(embeddings, top_k=k * 2 if self.rerank else k)
-        out = []
-        for pos, query in enumerate(queries):
-            if not results['ids'][pos]:
-                out.append([])
+        store = self.vector_store
+        col = store.collection
+        if col is None:
+            raise ValueError("No collection available. Create index first.")
+        fetch = k * 2 if self.rerank else k
+        hits = self._search_many(list(queries), fetch)
+        per_query: List[List[Dict]] = []
+        if isinstance(hits, dict):            # a duck-typed store's search_batch dict: lists per query
+            ids_l = docs_l = metas_l = None
+            hits = [(np.asarray(hits['distances'][p], dtype=np.float64), (hits['ids'][p], hits['documents'][p],
+                     hits['metadatas'][p] if hits.get('metadatas') else None)) for p in range(len(queries))]
+        else:
+            ids_l, docs_l, metas_l = col.ids, col.documents, col.metadatas
+        for query, (sc, rows) in zip(queries, hits):
+            if ids_l is None:
+                dist, (h_ids, h_docs, h_metas) = sc, rows
+                rows = np.arange(len(h_ids))
+            else:
+                valid = rows >= 0
+                rows, sc = rows[valid], sc[valid]
+                dist = (np.float32(1.0) - sc.astype(np.float32)).astype(np.float64)  # the store's distances, as search() returns them
+                h_ids, h_docs, h_metas = ids_l, docs_l, metas_l
+            if rows.size == 0:
+                logger.warning("No results found for query")
+                per_query.append([])
                 continue
-            chunks = self._hits_to_chunks(results['ids'][pos], results['documents'][pos],
-                                          results['metadatas'][pos], results['distances'][pos])
-            out.append(self._post_process(query, chunks, k))
-        return out
+            if self.distance_metric == 'cosine':                                          # _distance_to_similarity, vectorised (same fp64 ops)
+                d = np.minimum(np.maximum(dist, 0.0), 2.0)
+                score = np.minimum(np.maximum(1.0 - (d * d / 2.0), 0.0), 1.0)
+            else:
+                score = np.array([self._distance_to_similarity(float(x)) for x in dist])
+            keep = score >= self.similarity_threshold
+            chunks = [{'text': h_docs[r], 'score': float(s_), 'distance': float(d_), 'metadata': h_metas[r] if h_metas else {},
+                       'chunk_id': h_ids[r]}
+                      for r, s_, d_, ok in zip(rows.tolist(), score.tolist(), dist.tolist(), keep.tolist()) if ok]
+            if not chunks:
+                logger.warning(f"No chunks passed similarity threshold of {self.similarity_threshold}")
+                per_query.append([])
+                continue
+            if self.rerank and len(chunks) > k:
+                chunks = self._rerank(query, chunks, k)
+            else:
+                chunks = chunks[:k]
+            per_query.append(chunks)
+        if self.diversity_penalty > 0:
+            # ONE encoder pass for the chunk texts of every query (deduplicated), then the reference's greedy MMR per query
+            texts, index = [], {}
+            for chunks in per_query:
+                if len(chunks) > 1:
+                    for c in chunks:
+                        if c['text'] not in index:
+                            index[c['text']] = len(texts)
+                            texts.append(c['text'])
+            if texts:
+                vectors = self.embedding_model.embed(texts)
+                per_query = [self._apply_diversity(chunks, vectors=vectors[[index[c['text']] for c in chunks]])
+                             if len(chunks) > 1 else chunks for chunks in per_query]
+        return per_query
 
     def get_context_string(self, query: str, top_k: Optional[int] = None, separator: str = "\n\n") -> str:
         chunks = self.retrieve(query, top_k=top_k)
@@ -143,13 +250,15 @@ class ContextRetriever:
         chunks.sort(key=lambda c: c.get('rerank_score', c['score']), reverse=True)
         return chunks[:top_k]
 
-    def _apply_diversity(self, chunks: List[Dict]) -> List[Dict]:
+    def _apply_diversity(self, chunks: List[Dict], vectors=None) -> List[Dict]:
         """Greedy maximal-marginal-relevance re-ordering over re-embedded chunk texts:
-        value = lambda * score - (1 - lambda) * max(0, max cos to the already selected)."""
+        value = lambda * score - (1 - lambda) * max(0, max cos to the already selected).
+        `vectors` (retrieve_batch): the chunk texts' embeddings, already computed in one pass for the whole batch."""
         if len(chunks) <= 1:
             return chunks
         lam = 1.0 - self.diversity_penalty
-        vectors = self.embedding_model.embed([c['text'] for c in chunks])
+        if vectors is None:
+            vectors = self.embedding_model.embed([c['text'] for c in chunks])
         order = [0]
         pending = list(range(1, len(chunks)))
         while pending and len(order) < len(chunks):

@@ -33,7 +33,14 @@ typedef struct crs_encoder_desc {
   int32_t max_pos;
   float ln_eps;
   int32_t pooling;     /* CRS_POOL_*                                              */
+  int32_t flags;       /* CRS_ENC_* bits (ABI 3); 0 = default kernel selection     */
 } crs_encoder_desc;
+
+/* Kernel-form selection for query-batch forwards that run BESIDE a corpus scan (the role-lane layout of
+ * rag/_engine.py): only kernel forms of <= 48 KB of LDS per workgroup, so that a forward's workgroups fit on CUs that
+ * hold two scan workgroups (2 x 48 KB of 160 KB) instead of waiting for the scan to drain.  Same arithmetic, same
+ * results; slower when the forward runs alone. */
+#define CRS_ENC_SMALL_LDS 1
 
 /* Per-layer device pointers.  Matrices are fp16 row-major [out_features, in_features] exactly as
  * torch.nn.Linear stores them (y = x W^T + b); vectors are fp32. */

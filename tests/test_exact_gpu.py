@@ -8,8 +8,10 @@ top-k of all rows, and the escalation that restores exactness when the proof fai
     over-fetch cannot hold them all, the certificate must refuse, the escalation must return the oracle's fp32 ids;
   * more exact duplicates than the escalation list holds: status 2, and the store's retry with a longer list;
   * the store's DEFAULT config carries the property.
-Bar: ids identical to the oracle's, except between rows whose fp64 scores differ by < 3e-7 (fp32 summation order);
-scores within 1e-5 of the oracle's (north_star allows 1e-3)."""
+Bar: ids identical to the oracle's, except between rows whose fp64 scores differ by less than fp32 summation order can
+resolve (3e-7 at the |score| ~ 0.3 of random corpora; 2e-6 inside the near-duplicate bands, where |score| ~ 1 over 384 / 768
+terms: the oracle's sgemm and the kernel's FMA chain + butterfly round differently); scores within 1e-5 of the oracle's
+(north_star allows 1e-3)."""
 import numpy as np
 import pytest
 
@@ -108,7 +110,7 @@ def test_adversarial_near_ties_are_escalated_to_the_exact_ids(cuda, slab, n, d):
         s, i, st0, st1 = _search_exact(q, sl, sc, shadow, row_err, n, d, st_, k, k_scan)
         assert (st0 == 1).all(), f"{slab} k'={k_scan}: a query with 40 near-ties at the top was certified"
         assert (st1 == 1).all()                             # escalated, no overflow
-        _assert_topk(s, i, q.cpu().numpy(), shadow.cpu().numpy(), k, f"{slab} k'={k_scan}")
+        _assert_topk(s, i, q.cpu().numpy(), shadow.cpu().numpy(), k, f"{slab} k'={k_scan}", tol=2e-6)
         # and the un-escalated re-rank really is wrong here (the test would be vacuous otherwise)
         s_, i_, _, _ = _search_exact(q, sl, sc, shadow, row_err, n, d, st_, k, k_scan, escalate=False)
         assert (np.sort(i_, 1) != np.sort(i, 1)).any()
@@ -138,7 +140,7 @@ def test_small_shards_and_partial_batches(cuda):
     q = torch.cat([centres, torch.nn.functional.normalize(torch.randn((16, d), generator=g, device=cuda), dim=1)]).contiguous()
     s, i, st0, st1 = _search_exact(q, sl, sc, shadow, row_err, n, d, nat.SLAB_F16, 10, 16)
     assert (st0[:4] == 1).all() and (st0[4:] == 0).mean() > 0.8
-    _assert_topk(s, i, q.cpu().numpy(), shadow.cpu().numpy(), 10, "mixed batch")
+    _assert_topk(s, i, q.cpu().numpy(), shadow.cpu().numpy(), 10, "mixed batch", tol=2e-6)
 
 
 def test_list_overflow_sets_status_2_and_a_longer_list_resolves_it(cuda):
@@ -190,7 +192,7 @@ def test_store_default_config_returns_the_fp32_ranking(cuda, dtype):
     rows_h = store.collection.shadow[:n].cpu().numpy()
     got_i = np.array([[int(c.split("_")[1]) for c in row] for row in res["ids"]])
     got_s = np.array([[1.0 - x for x in row] for row in res["distances"]], dtype=np.float32)
-    _assert_topk(got_s, got_i, q, rows_h, 10, f"store {dtype}")
+    _assert_topk(got_s, got_i, q, rows_h, 10, f"store {dtype}", tol=2e-6)
     assert set(got_i[0]) <= set(dup.tolist())
     # opting out: the plain slab ranking, no shadow, no certificate
     plain = VectorStore({"collection_name": "plain", "refine_fp32": False, "index_dtype": dtype})
