@@ -471,7 +471,7 @@ def main():
     # ids per batch), final lists against the exact ranking of the UNQUANTISED fp32 rows of every shard (fp64 accumulation)
     # -- catches quantisation loss as well as any mix-up of query order, id bases, wire layout or merge.
     def run_all(engine):
-        fs, fi, fst = [], [], []
+        fs, fi, fst, fq = [], [], [], []
         for b0 in range(0, n_batches, n_ctx):
             nb = min(n_ctx, n_batches - b0)
             for i in range(nb):
@@ -483,17 +483,14 @@ def main():
             torch.cuda.synchronize()
             for i in range(nb):
                 s_, i_, st_ = engine.outputs(i)
+                c_ = engine.ctxs[i]
                 fs.append(s_.clone()); fi.append(i_.clone()); fst.append(st_.clone())
-        return torch.cat(fs), torch.cat(fi), torch.cat(fst)
+                fq.append((c_.q_all32 if engine.gather_q else c_.q_out).clone())     # the fp32 queries this batch searched with
+        return torch.cat(fs), torch.cat(fi), torch.cat(fst), torch.cat(fq)
 
-    fin_s, fin_i, fin_st = run_all(eng)
-    if strong:
-        q_truth = flat_q
-    else:                           # weak scaling: the batch every rank searched = all ranks' queries, gathered
-        q_truth = torch.empty((n_batches, nq_all, dim), dtype=torch.float32, device=dev)
-        for b in range(n_batches):
-            dist.all_gather_into_tensor(q_truth[b], q32_all[b].contiguous()) if multi else q_truth[b].copy_(q32_all[b])
-        q_truth = q_truth.view(-1, dim)
+    # ground-truth queries = the embeddings the engine itself produced and searched with (its encoder runs the small-LDS
+    # kernel forms under role lanes: same arithmetic, different K-chunking, so the last bits differ from a plain forward)
+    fin_s, fin_i, fin_st, q_truth = run_all(eng)
     nq_total = q_truth.shape[0]
     gt_s = torch.empty((nq_total, k), dtype=torch.float64, device=dev)
     gt_i = torch.empty((nq_total, k), dtype=torch.int64, device=dev)
@@ -537,7 +534,7 @@ def main():
     eng_other = make_engine(not refine, exact_mode)
     eng_other.use_graph = False
     eng_other.warm_up()
-    oth_s, oth_i, _ = run_all(eng_other)
+    oth_s, oth_i, _, _ = run_all(eng_other)
     torch.cuda.synchronize()
     recall_other = float(recall_rows(oth_i, gt_i).mean().item())
     err_other = float((oth_s.double() - gt_s).abs().max().item())

@@ -38,6 +38,8 @@ int device_cus() {
 }
 
 
+constexpr int kW1MaxDump = 256;
+
 struct Plan {
   int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
   int nqb;                                 // query blocks (64 queries each; 32 * wide_nw for the wide kernel)
@@ -66,9 +68,13 @@ bool tb_enabled() {   // CRS_SCAN_TB=0: always use the threshold/compaction kern
   return v == 1;
 }
 
-// workspace: [shared thresholds | partial scores | partial rows | stage-1 winners (scores, ids)]
+// workspace: [shared thresholds | partial scores | partial rows | stage-1 winners (scores, ids) | two-level merge scratch
+// (scores, ids): one k-entry list per 8192 candidates of a query (merge.hip)]
+size_t inter_lists(size_t part_elems, int nq) { return part_elems / ((size_t)nq * 4096) + 2; }   // >= merge_slices(nwg, kp)
 size_t ws_bytes(size_t part_elems, int nq, int k) {
-  return tau_bytes(nq) + 2 * align_up(part_elems * 4, 256) + align_up((size_t)nq * k * 4, 256) + align_up((size_t)nq * k * 8, 256);
+  const size_t inter = (size_t)nq * inter_lists(part_elems, nq) * k;
+  return tau_bytes(nq) + 2 * align_up(part_elems * 4, 256) + align_up((size_t)nq * k * 4, 256) + align_up((size_t)nq * k * 8, 256) +
+         align_up(inter * 4, 256) + align_up(inter * 8, 256);
 }
 
 int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
@@ -81,9 +87,10 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
   // kernel family: one of the tile-best kernels, or the classic threshold/compaction scan.  The register-chain forms
   // hold k <= 16; the dump form (short streams) has no such limit and serves k <= 64.  For k > 16 the family is
   // therefore only known once the stream length is: plan for tile-best first, fall back to classic if it has to chain.
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    const bool allow_tb = attempt == 0 && tb_enabled();
-    p->w1_qg = (allow_tb && slab_type == CRS_SLAB_F16) ? crs::scan_w1_queries_per_wg(nq, k, p->pdim) : 0;
+  bool allow_w1 = true;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const bool allow_tb = attempt < 2 && tb_enabled();
+    p->w1_qg = (allow_tb && allow_w1 && slab_type == CRS_SLAB_F16) ? crs::scan_w1_queries_per_wg(nq, k, p->pdim) : 0;
     p->wide_nw = (allow_tb && !p->w1_qg && slab_type == CRS_SLAB_F16 && k <= 16) ? crs::scan_wide_waves(nq, k, p->pdim) : 0;
     p->tb_nw = 0;
     if (allow_tb && !p->w1_qg && !p->wide_nw && slab_type == CRS_SLAB_F16)
@@ -108,6 +115,10 @@ int make_plan(int nq, int dim, int k, int64_t n_rows, int slab_type, Plan* p) {
     if (p->w1_qg) {                          // dump: every tile's representative goes to the partial list
       p->kp = (p->n_tiles + p->nwg - 1) / p->nwg;
       p->group_best = 1;
+      // the dump's workspace and merge input grow with the shard (nq * n_rows / 32 entries): past kW1MaxDump entries per
+      // (query, stream) -- 1 M rows x 768 at 256 queries is 123 -- the bounded 8-wave chain kernels take over
+      // (10 M x 768 at 256 queries would otherwise be 640 MB of workspace and 312 k candidates per query)
+      if (p->kp > kW1MaxDump) { allow_w1 = false; continue; }
     } else if (p->wide_nw) {   // register chain of the K best tile representatives per lane
       p->kp = 2 * crs::scan_wide_slots(k);
       p->group_best = 1;
@@ -265,15 +276,18 @@ int crs_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const v
   int e = run_scan(p, q16_dev, nq, slab_type, slab_dev, scales_dev, n_rows, k, workspace_dev, st, &ps, &pr);
   if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
   if (e) return hip_fail((hipError_t)e, "scan launch");
+  float* win_s = reinterpret_cast<float*>(reinterpret_cast<char*>(pr) + align_up(p.part_elems * 4, 256));
+  int64_t* win_i = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(win_s) + align_up((size_t)nq * k * 4, 256));
+  float* inter_s = reinterpret_cast<float*>(reinterpret_cast<char*>(win_i) + align_up((size_t)nq * k * 8, 256));
+  int64_t* inter_i = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(inter_s) + align_up((size_t)nq * inter_lists(p.part_elems, nq) * k * 4, 256));
+  if ((size_t)crs::merge_slices(p.nwg, p.kp) > inter_lists(p.part_elems, nq)) inter_s = nullptr;   // (cannot happen: see inter_lists)
   if (!p.group_best) {
-    e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, id_base, out_scores_dev, out_ids_dev, st);
+    e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, id_base, out_scores_dev, out_ids_dev, inter_s, inter_i, st);
     if (e) return hip_fail((hipError_t)e, "merge launch");
     return CRS_OK;
   }
   // group-best variants: k best representatives (local rows) -> their row groups re-scored and ranked
-  float* win_s = reinterpret_cast<float*>(reinterpret_cast<char*>(pr) + align_up(p.part_elems * 4, 256));
-  int64_t* win_i = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(win_s) + align_up((size_t)nq * k * 4, 256));
-  e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, 0, win_s, win_i, st);
+  e = crs::merge_launch_i32(ps, pr, p.nwg, nq, p.kp, k, 0, win_s, win_i, inter_s, inter_i, st);
   if (e) return hip_fail((hipError_t)e, "merge launch");
   e = (slab_type == CRS_SLAB_I8)
           ? crs::refine_i8_launch(reinterpret_cast<const _Float16*>(q16_dev), nq, p.pdim, slab_dev, scales_dev, (int)n_rows, win_s,

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
                                                         int k_in, int k_out, size_t list_stride,
                                                         size_t id_list_stride, size_t q_stride, int64_t id_base,
                                                         float* __restrict__ out_s,
-                                                        int64_t* __restrict__ out_i) {
+                                                        int64_t* __restrict__ out_i, int lists_per_slice) {
   __shared__ float sh_sorted[4][64];
   __shared__ float sh_cs[kCap];
   __shared__ IdT sh_ci[kCap];
@@ -71,6 +71,13 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
 
   const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Two-level form (merge_launch_i32, > 8192 candidates per query): workgroup (q, y) ranks only lists
+  // [y L, (y + 1) L) of the query and leaves their k_out best at out[(q * gridDim.y + y) * k_out]; a second launch merges
+  // those gridDim.y short lists.  One-level launches have gridDim.y == 1 and lists_per_slice == nlists.
+  const int first_list = blockIdx.y * lists_per_slice;
+  nlists = (nlists - first_list < lists_per_slice) ? nlists - first_list : lists_per_slice;
+  scores += (size_t)first_list * list_stride;
+  ids += (size_t)first_list * id_list_stride;
   const int m = nlists * k_in;
   // candidate e = (list e / k_in, slot e % k_in) lives at list*list_stride + q*q_stride + slot
   // (== e when a query's lists are contiguous).  Threads walk the entries in passes (below), eight passes at a
@@ -115,8 +122,8 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
       BODY;                                                                              \
     }                                                                                    \
   }
-  float* os = out_s + (size_t)q * k_out;
-  int64_t* oi = out_i + (size_t)q * k_out;
+  float* os = out_s + ((size_t)q * gridDim.y + blockIdx.y) * k_out;
+  int64_t* oi = out_i + ((size_t)q * gridDim.y + blockIdx.y) * k_out;
 
   if (tid == 0) sh_cnt = 0;
   for (int r = tid; r < k_out; r += kThreads) { os[r] = kNegInf; oi[r] = -1; }
@@ -226,10 +233,27 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
 }  // namespace
 
 // stage-2 layout: [nq, nlists, k_in] (a query's candidates are contiguous)
+// Slices of a two-level stage-2 merge: whole lists, at most 8192 candidates (the register-cached path) per workgroup.
+int merge_slices(int nlists, int k_in) {
+  if ((long)nlists * k_in <= 8192 || k_in > 8192) return 1;
+  const int per = 8192 / k_in;
+  return (nlists + per - 1) / per;
+}
+
 int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,
-                     int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream) {
+                     int64_t id_base, float* out_scores, int64_t* out_ids, float* inter_s, int64_t* inter_i, hipStream_t stream) {
+  const int slices = (inter_s && inter_i) ? merge_slices(nlists, k_in) : 1;
+  if (slices > 1) {
+    // level 1: every slice's k_out best (local rows, id_base 0) -> [nq, slices, k_out]; level 2: those short lists
+    const int per = 8192 / k_in;
+    hipLaunchKernelGGL((merge_kernel<int>), dim3(nq, slices), dim3(kThreads), 0, stream, scores, rows, nlists, k_in, k_out,
+                       (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, (int64_t)0, inter_s, inter_i, per);
+    hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, inter_s, inter_i, slices, k_out, k_out,
+                       (size_t)k_out, (size_t)k_out, (size_t)slices * k_out, id_base, out_scores, out_ids, slices);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL((merge_kernel<int>), dim3(nq), dim3(kThreads), 0, stream, scores, rows, nlists,
-                     k_in, k_out, (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids);
+                     k_in, k_out, (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids, nlists);
   return (int)hipGetLastError();
 }
 
@@ -238,7 +262,7 @@ int merge_launch_i64(const float* scores, const int64_t* ids, int nlists, int nq
   // all-gather layout: [nlists, nq, k_in]
   hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, scores, ids,
                      nlists, k_in, k_out, (size_t)nq * k_in, (size_t)nq * k_in, (size_t)k_in, (int64_t)0, out_scores,
-                     out_ids);
+                     out_ids, nlists);
   return (int)hipGetLastError();
 }
 
@@ -248,7 +272,7 @@ int merge_launch_wire(const void* wire, size_t block_bytes, size_t scores_off, i
   const int64_t* ids = reinterpret_cast<const int64_t*>(wire);
   const float* scores = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wire) + scores_off);
   hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, scores, ids, nlists, k_in, k_out,
-                     block_bytes / 4, block_bytes / 8, (size_t)k_in, (int64_t)0, out_scores, out_ids);
+                     block_bytes / 4, block_bytes / 8, (size_t)k_in, (int64_t)0, out_scores, out_ids, nlists);
   return (int)hipGetLastError();
 }
 

@@ -58,8 +58,11 @@ int scan_w1_queries_per_wg(int nq, int k, int pdim);   // 0: not applicable; els
 int scan_launch_w1(const ScanArgs& a, int pdim, hipStream_t stream);
 
 // merge.hip
+// inter_s / inter_i: [nq, merge_slices(nlists, k_in), k_out] scratch of the two-level form (> 8192 candidates per query);
+// null = always one level
+int merge_slices(int nlists, int k_in);
 int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,
-                     int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream);
+                     int64_t id_base, float* out_scores, int64_t* out_ids, float* inter_s, int64_t* inter_i, hipStream_t stream);
 int merge_launch_i64(const float* scores, const int64_t* ids, int nlists, int nq, int k_in, int k_out,
                      float* out_scores, int64_t* out_ids, hipStream_t stream);
 

@@ -66,13 +66,13 @@ class RetrievalEngine:
         self.multi = dist is not None
         self.k, self.seq = int(top_k), int(seq)
         self.refine = bool(refine) and view.shadow is not None
-        self.k_scan = min(nat.MAX_K, max(self.k, int(k_scan))) if self.refine else self.k
         self.exact = (view.slab_type == nat.SLAB_F16) if exact == "auto" else bool(exact)
         self.exact = self.exact and self.refine
         self.exact_cap = int(exact_cap)
         self.encode = bool(encode)
         qb = int(queries_per_batch)
         self.nq_all = qb * world if queries_per_rank else qb
+        self.k_scan = nat.overfetch(self.nq_all, self.k, int(k_scan)) if self.refine else self.k
         shard_w = 1
         if self.multi and not queries_per_rank and encode_shard > 1 and qb % encode_shard == 0:
             shard_w = encode_shard

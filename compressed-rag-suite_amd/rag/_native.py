@@ -226,6 +226,17 @@ def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out
     return out_scores, out_ids
 
 
+def overfetch(nq: int, top_k: int, want: int = 32) -> int:
+    """Candidates the scan fetches for the fp32 re-rank: `want` (32: the certificate then holds for all but ~1e-5 of random
+    queries), except that launches of more than 64 queries keep to 16 when top_k allows -- the large-batch kernels
+    (scan_wide.hip) carry a 16-slot chain, and 32 candidates would send those launches to the 64-query kernel once per
+    query block.  Never below top_k, never above MAX_K."""
+    k = max(int(top_k), int(want))
+    if nq > 64 and top_k <= 16:
+        k = max(int(top_k), min(int(want), 16))
+    return min(MAX_K, k)
+
+
 def exact_workspace_bytes(nq: int, cap: int = EXACT_CAP) -> int:
     return int(load().crs_exact_workspace_bytes(int(nq), int(cap)))
 

@@ -410,7 +410,7 @@ class VectorStore:
             s, i = self._topk_large(sh, q32, slab, scales, shadow if refine else None, n, top_k)
         else:
             q16 = nat.queries_to_f16(q32, sh.slab_type)
-            k_scan = min(nat.MAX_K, max(top_k, self.refine_overfetch)) if refine else top_k
+            k_scan = nat.overfetch(nq, top_k, self.refine_overfetch) if refine else top_k
             s, i = nat.cosine_topk(q16, slab, n, sh.dim, k_scan, slab_type=sh.slab_type, scales=scales,
                                    workspace=sh.workspace(nq, k_scan, n))
             if refine:
@@ -585,6 +585,17 @@ class VectorStore:
             return None
         from rag._engine import ShardView
         return ShardView(sh.slab, sh.scales, sh.shadow if sh.refine_fp32 else None, sh.n, sh.dim, sh.slab_type, 0, sh.row_err_max())
+
+    def rows_f32(self, rows):
+        """The fp32 rows the store kept for these sidecar rows (numpy [len(rows), dim]; the normalised encoder output of the
+        chunks as indexed), or None when it keeps none / the layout is not a single identity shard."""
+        import torch
+        col = self.collection
+        if col is None or len(col.shards) != 1 or not col.shards[0].identity or col.shards[0].shadow is None:
+            return None
+        sh = col.shards[0]
+        idx = torch.as_tensor(np.asarray(rows, dtype=np.int64), device=sh.device)
+        return sh.shadow[idx].cpu().numpy()
 
     def search_rows(self, query_embeddings, top_k: int):
         """search_batch without the sidecar lookup: (scores fp32 [nq, k], sidecar rows int64 [nq, k]) as numpy, best first,

@@ -35,6 +35,13 @@ class ContextRetriever:
         self.rerank = config.get('rerank', False)
         self.diversity_penalty = config.get('diversity_penalty', 0.0)
         self.batch_queries = int(config.get('batch_queries', 64))    # additive: queries per launch of retrieve_batch's engine
+        # additive: where the MMR step takes the chunks' vectors from.  'reembed' = encode the chunk texts again, as the
+        # reference does (rag/retrieval.py:238-239); 'index' = the fp32 rows the store kept when those very texts were
+        # indexed (the same encoder's output for the same text: equal up to the rounding of a different batch composition;
+        # no tokenisation, no encoder pass); 'auto' = retrieve() re-embeds (reference parity), retrieve_batch() reads the index
+        self.mmr_vectors = config.get('mmr_vectors', 'auto')
+        if self.mmr_vectors not in ('auto', 'reembed', 'index'):
+            raise ValueError(f"mmr_vectors must be 'auto', 'reembed' or 'index', got {self.mmr_vectors!r}")
         self._engine, self._engine_key = None, None
         self.distance_metric = self._get_distance_metric()
         logger.info(f"Using distance metric: {self.distance_metric}")
@@ -107,6 +114,8 @@ class ContextRetriever:
             metas = results['metadatas'][0] if results['metadatas'] else None
             chunks = self._hits_to_chunks(results['ids'][0], results['documents'][0], metas,
                                           results['distances'][0])
+            if self.mmr_vectors == 'index' and self.diversity_penalty > 0:
+                return self.retrieve_batch([query], top_k=top_k)[0] if filters is None else self._post_process(query, chunks, k)
             return self._post_process(query, chunks, k)
         except Exception as e:
             logger.error(f"Retrieval failed: {e}")
@@ -183,6 +192,7 @@ class ContextRetriever:
         fetch = k * 2 if self.rerank else k
         hits = self._search_many(list(queries), fetch)
         per_query: List[List[Dict]] = []
+        row_of: Dict[int, int] = {}           # id(chunk dict) -> sidecar row (our store only)
         if isinstance(hits, dict):            # a duck-typed store's search_batch dict: lists per query
             ids_l = docs_l = metas_l = None
             hits = [(np.asarray(hits['distances'][p], dtype=np.float64), (hits['ids'][p], hits['documents'][p],
@@ -211,6 +221,9 @@ class ContextRetriever:
             chunks = [{'text': h_docs[r], 'score': float(s_), 'distance': float(d_), 'metadata': h_metas[r] if h_metas else {},
                        'chunk_id': h_ids[r]}
                       for r, s_, d_, ok in zip(rows.tolist(), score.tolist(), dist.tolist(), keep.tolist()) if ok]
+            if ids_l is not None:
+                for c_, r_ in zip(chunks, [r for r, ok in zip(rows.tolist(), keep.tolist()) if ok]):
+                    row_of[id(c_)] = r_
             if not chunks:
                 logger.warning(f"No chunks passed similarity threshold of {self.similarity_threshold}")
                 per_query.append([])
@@ -220,7 +233,18 @@ class ContextRetriever:
             else:
                 chunks = chunks[:k]
             per_query.append(chunks)
-        if self.diversity_penalty > 0:
+        from_index = self.mmr_vectors in ('auto', 'index') and ids_l is not None and hasattr(store, 'rows_f32')
+        if self.diversity_penalty > 0 and from_index:
+            # the chunks' vectors straight from the index (one gather for the whole batch), then the reference's greedy MMR
+            need = sorted({row_of[id(c)] for chunks in per_query if len(chunks) > 1 for c in chunks})
+            vecs = store.rows_f32(need) if need else None
+            if vecs is None:
+                from_index = False
+            else:
+                at = {r: p for p, r in enumerate(need)}
+                per_query = [self._apply_diversity(chunks, vectors=vecs[[at[row_of[id(c)]] for c in chunks]])
+                             if len(chunks) > 1 else chunks for chunks in per_query]
+        if self.diversity_penalty > 0 and not from_index:
             # ONE encoder pass for the chunk texts of every query (deduplicated), then the reference's greedy MMR per query
             texts, index = [], {}
             for chunks in per_query:
@@ -253,27 +277,34 @@ class ContextRetriever:
     def _apply_diversity(self, chunks: List[Dict], vectors=None) -> List[Dict]:
         """Greedy maximal-marginal-relevance re-ordering over re-embedded chunk texts:
         value = lambda * score - (1 - lambda) * max(0, max cos to the already selected).
-        `vectors` (retrieve_batch): the chunk texts' embeddings, already computed in one pass for the whole batch."""
+        `vectors` (retrieve_batch): the chunks' embeddings, already at hand for the whole batch.
+
+        Same values as the reference's triple loop (rag/retrieval.py:246-275), computed once each: the reference
+        re-evaluates cos(candidate, chosen) for every chosen chunk in every round (~k^3/3 dot products and twice as many
+        norms); a candidate's running maximum only ever changes by the newest chosen chunk, and max() of floats does not
+        depend on the order it is taken in, so one cos per (candidate, newly chosen) pair -- k^2/2 -- gives bit-identical
+        `closest`, `value` and order (pinned by tests/golden/retrieve_cases.json)."""
         if len(chunks) <= 1:
             return chunks
         lam = 1.0 - self.diversity_penalty
         if vectors is None:
             vectors = self.embedding_model.embed([c['text'] for c in chunks])
+        norms = [np.linalg.norm(v) for v in vectors]
         order = [0]
         pending = list(range(1, len(chunks)))
+        closest = {cand: 0.0 for cand in pending}
+        newest = 0
         while pending and len(order) < len(chunks):
             winner, winner_value = None, -float('inf')
             for cand in pending:
-                closest = 0.0
-                for chosen in order:
-                    cos = np.dot(vectors[cand], vectors[chosen]) / (
-                        np.linalg.norm(vectors[cand]) * np.linalg.norm(vectors[chosen]))
-                    closest = max(closest, cos)
-                value = lam * chunks[cand]['score'] - (1 - lam) * closest
+                cos = np.dot(vectors[cand], vectors[newest]) / (norms[cand] * norms[newest])
+                closest[cand] = max(closest[cand], cos)
+                value = lam * chunks[cand]['score'] - (1 - lam) * closest[cand]
                 if value > winner_value:
                     winner, winner_value = cand, value
             if winner is None:
                 break
             order.append(winner)
             pending.remove(winner)
+            newest = winner
         return [chunks[i] for i in order]

@@ -111,7 +111,9 @@ def cosine_topk_ref(q: np.ndarray, slab: np.ndarray, k: int, *, scales: np.ndarr
     for lo in range(0, n, block):
         hi = min(n, lo + block)
         t0 = time.perf_counter()
-        s = qa @ slab[lo:hi].astype(accumulate).T
+        # (rows x d) @ (d x nq), transposed afterwards: the same dot products as q @ rows^T, but BLAS gets a tall
+        # row-major left operand (the other orientation runs ~7x slower in OpenBLAS at these shapes)
+        s = np.ascontiguousarray((slab[lo:hi].astype(accumulate, copy=False) @ qa.T).T)
         if scales is not None:
             s = s * scales[lo:hi].astype(accumulate)[None, :]
         s = s.astype(np.float32, copy=False)

@@ -154,3 +154,32 @@ def test_chain_mode_ties_across_lanes_and_streams(cuda):
     assert (gs[0] == gs[0][0]).all()
     rs, ri = scan_ref.cosine_topk_ref(q, c, 10, accumulate=np.float64)
     assert np.mean([scan_ref.recall_at_k(gi[r], ri[r]) for r in range(8)]) > 0.99
+
+
+def test_w2_dump_is_bounded_and_the_fallback_is_exact(cuda):
+    """The 256-query kernel for 768-element rows dumps every tile's representative: workspace and merge input grow
+    with the shard.  Past 256 entries per (query, stream) the planner must hand over to the bounded chain kernels
+    (10 M x 768 at 256 queries would be 640 MB of workspace, 312 k merge candidates per query), and both sides of
+    that switch -- and the two-level merge that serves dumps of > 8192 candidates -- return the oracle's answer."""
+    import torch
+    from rag import _native as nat
+    assert "scan_w2" in nat.scan_plan_describe(256, 768, 10, 1_000_000)                 # C3: the dump form
+    assert "scan_w2" in nat.scan_plan_describe(256, 768, 10, 2_000_000)                 # 62500 tiles / 256 streams = 245
+    plan_big = nat.scan_plan_describe(256, 768, 10, 10_000_000)
+    assert "scan_w2" not in plan_big, plan_big
+    assert nat.scan_workspace_bytes(256, 768, 10, 10_000_000) < 64 << 20
+    assert nat.scan_workspace_bytes(1024, 768, 10, 10_000_000) < 256 << 20
+    n, d, nq, k = 2_200_000, 768, 256, 10                                                # 68750 tiles / 256 = 269 > 256
+    assert "scan_w2" not in nat.scan_plan_describe(nq, d, k, n)
+    g = torch.Generator(device=cuda); g.manual_seed(5)
+    slab = torch.empty((n, d), dtype=torch.float16, device=cuda)
+    for lo in range(0, n, 250_000):
+        m = min(250_000, n - lo)
+        nat.slab_append_f32(torch.randn((m, d), generator=g, device=cuda), slab, lo, nat.SLAB_F16)
+    q16 = nat.queries_to_f16(torch.randn((nq, d), generator=g, device=cuda))
+    for rows in (n, 1_000_000):                                                          # chain fallback; dump + two-level merge
+        s, i = nat.cosine_topk(q16, slab, rows, d, k)
+        torch.cuda.synchronize()
+        rs, ri = scan_ref.cosine_topk_ref(q16.cpu().numpy(), slab[:rows].cpu().numpy(), k)
+        assert (i.cpu().numpy() == ri).mean() > 0.999
+        assert np.abs(s.cpu().numpy() - rs).max() < 2e-5
