@@ -20,6 +20,12 @@ int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, con
 // enc_gemm_stream.hip: row-streaming variant for short contractions (K in {128, 256, 384, 512}) and many rows:
 // W fragments resident in VGPRs, A streamed once per 128-column block
 bool gemm_stream_supported(int k);
+// enc_gemm8.hip: 256 x 256 x 64 tiles, eight-barrier phase schedule (whole tiles only, K % 128 == 0)
+bool gemm8_applies(int m, int n, int k, int mode);
+int gemm8_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k,
+                 int mode, hipStream_t stream);
+int gemm8_splitk(int m, int n, int k);   // K slabs of the split-K form for this shape (0: not applicable)
+int gemm8_splitk_launch(const _Float16* a, const _Float16* w, float* partials, int m, int n, int k, int splits, hipStream_t stream);
 // enc_gemm_big.hip: 256-row tiles for large M (index build)
 int gemm_big_block_n(int m, int n, int k, int mode);   // 0: not applicable
 int gemm_big_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k,

@@ -71,6 +71,8 @@ Layout make_layout(const crs_encoder_desc* d, int batch, int seq) {
   int split = 1;
   if (use_panel((int)t, (int)f)) split = crs::gemm_panel_splits((int)f, (int)t);
   if (use_panel((int)t, (int)h) && crs::gemm_panel_splits((int)h, (int)t) > split) split = crs::gemm_panel_splits((int)h, (int)t);
+  if (crs::gemm8_splitk((int)t, (int)h, (int)f) > split) split = crs::gemm8_splitk((int)t, (int)h, (int)f);
+  if (crs::gemm8_splitk((int)t, (int)h, (int)h) > split) split = crs::gemm8_splitk((int)t, (int)h, (int)h);
   l.max_split = split;
   l.x32 = off; off += up256(t * h * 4);
   l.y32 = off; off += up256(t * h * 4 * split);
@@ -154,7 +156,10 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
   // per workgroup for a handful of tiles
   static int panel_multi = -1;
   if (panel_multi < 0) { const char* e = getenv("CRS_ENC_PANEL_MULTI"); panel_multi = (e && e[0] == '0') ? 0 : 1; }
-  const bool single_h = T <= kPanelMaxTokens && crs::gemm_panel_chunk(H) != 0 && (crs::gemm_panel_chunk(H) == H || panel_multi);
+  // (the phase-scheduled 256 x 256 kernel takes QKV / FFN-up as soon as it has a chip's worth of tiles: bge-base from 4096 tokens)
+  const bool single_h = T <= kPanelMaxTokens && crs::gemm_panel_chunk(H) != 0 && (crs::gemm_panel_chunk(H) == H || panel_multi) &&
+                        !crs::gemm8_applies(T, 3 * H, H, 0);
+  const int s8_h = (!panel_h) ? crs::gemm8_splitk(T, H, H) : 0, s8_f = (!panel_f) ? crs::gemm8_splitk(T, H, F) : 0;
   // short sequences in the launch-bound regime: QKV projection + attention as one kernel (enc_qkvattn.hip)
   const int small = (d->flags & CRS_ENC_SMALL_LDS) ? 1 : 0;
   const bool fuse_qa = T <= kPanelMaxTokens && !small && qa_enabled() && crs::qkv_attn_supported(H, d->heads, seq);
@@ -172,6 +177,9 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
     } else if (panel_h) {
       CRS_TRY(crs::gemm_panel_launch(ctx, (const _Float16*)L.w_o, nullptr, y32, T, H, H, 3, small, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(H, T), L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
+    } else if (s8_h) {
+      CRS_TRY(crs::gemm8_splitk_launch(ctx, (const _Float16*)L.w_o, y32, T, H, H, s8_h, st), "out gemm (split-K)");
+      CRS_TRY(crs::layernorm_launch(y32, s8_h, L.b_o, x32, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ctx, (const _Float16*)L.w_o, L.b_o, x32, y32, T, H, H, 2, st), "out gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln1_g, L.ln1_b, d->ln_eps, T, H, x32, x16, st), "layernorm 1");
@@ -183,6 +191,9 @@ static int encoder_forward(const crs_encoder_desc* d, const crs_encoder_weights*
     } else if (panel_f) {
       CRS_TRY(crs::gemm_panel_launch(ffn, (const _Float16*)L.w_down, nullptr, y32, T, H, F, 3, small, st), "ffn down gemm");
       CRS_TRY(crs::layernorm_launch(y32, crs::gemm_panel_splits(F, T), L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
+    } else if (s8_f) {
+      CRS_TRY(crs::gemm8_splitk_launch(ffn, (const _Float16*)L.w_down, y32, T, H, F, s8_f, st), "ffn down gemm (split-K)");
+      CRS_TRY(crs::layernorm_launch(y32, s8_f, L.b_down, x32, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");
     } else {
       CRS_TRY(crs::gemm_f16_launch(ffn, (const _Float16*)L.w_down, L.b_down, x32, y32, T, H, F, 2, st), "ffn down gemm");
       CRS_TRY(crs::layernorm_launch(y32, 1, nullptr, nullptr, L.ln2_g, L.ln2_b, d->ln_eps, T, H, x32, x16, st), "layernorm 2");

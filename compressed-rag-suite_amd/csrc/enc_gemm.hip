@@ -377,6 +377,7 @@ int gemm_f16_launch(const _Float16* a, const _Float16* w, const float* bias, con
                     void* out, int m, int n, int k, int mode, hipStream_t stream) {
   // short contraction, many rows, wide output (the index-build side's QKV and FFN-up projections): the tiled kernel
   // below spends as long in its prologue and epilogue as in its K / 64 steps; stream rows past resident W
+  if (gemm8_applies(m, n, k, mode)) return gemm8_launch(a, w, bias, residual, out, m, n, k, mode, stream);
   if (gemm_big_block_n(m, n, k, mode) != 0) return gemm_big_launch(a, w, bias, residual, out, m, n, k, mode, stream);
   if (m >= 512 && n >= 512 && mode != 2 && gemm_stream_supported(k) && stream_enabled())
     return gemm_stream_launch(a, w, bias, residual, out, m, n, k, mode, stream);

@@ -1,0 +1,307 @@
+// enc_gemm8.hip -- 256 x 256 x 64 MFMA GEMM with an eight-barrier-per-k-tile phase schedule (gfx950).
+//
+//   C[M, N] = epilogue( A[M, K] x W[N, K]^T + bias[N] )        mode 0: fp16; 1: erf-GELU, fp16; 2: + residual fp32, fp32
+//
+// The structure the CDNA4 guide measures at ~1.3 PFLOP/s on random fp16/bf16 data (cdna_hip_programming.md section 5,
+// "256^2 8-phase template"), written for this library's operand layout (W stored [N, K] like torch.nn.Linear):
+//   * one 512-thread workgroup per CU owns a 256 x 256 output tile; eight waves as 2 (rows) x 4 (columns), wave tile
+//     128 x 64 = 8 x 4 accumulator tiles of v_mfma_f32_16x16x32_f16 (the shape the chip holds the higher clock on);
+//   * LDS: two k-tile buffers of four 16 KB HALF tiles (A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255,
+//     128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7: conflict-free ds_read_b128), filled by LDS-DMA
+//     (global_load_lds_dwordx4; the swizzle is applied to the SOURCE address, the transfer writes LDS linearly);
+//   * a k-tile is four PHASES of 16 MFMAs (one 64 x 32 quadrant of the wave tile x K = 64), each between two barriers;
+//     the two waves of a SIMD (wave w and w + 4 = the two row groups) run half a phase apart, so one multiplies while
+//     the other reads fragments and issues transfers;
+//   * every phase issues ONE half tile, three to six phases ahead of its first use, behind a counted vmcnt(6) once per
+//     k-tile (three half tiles stay in flight across the barriers; the loop never drains to vmcnt(0)).
+// Hazards (why this order is safe; barrier numbers per k-tile: group 0 passes X_p = 2p, Y_p = 2p + 1, group 1 X_p = 2p + 1,
+// Y_p = 2p + 2):
+//   RAW  a half tile is read one phase after the barrier that follows EVERY wave's vmcnt for it: the wait sits before X_3
+//        of k-tile t (numbers 6 / 7), the first reads of k-tile t + 1 come after Y_3 (7 / 8);
+//   WAR  fragment reads are retired (lgkmcnt(0)) BEFORE the wave's X barrier, and a half tile is re-filled only by waves
+//        that have passed a barrier after that X: W halves (read in phase 0) from phase 1 on, the A half of group 0
+//        (last read phase 2, retired before number 4) in phase 3 (after 5 / 6), the A half of group 1 (retired before 5)
+//        in phase 0 of the next k-tile (after 7 / 8).
+// The epilogue goes through wave-private LDS tiles (144-byte / 272-byte rows) so that global stores are 16 bytes per
+// lane and 128 / 256 bytes contiguous per row.
+#include "enc.h"
+#include "enc_gelu.h"
+#include "lds_dma.h"
+
+#include <stdlib.h>
+
+namespace crs {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PM = 256, PN = 256, PK = 64;
+constexpr int kP8Threads = 512;
+constexpr int kHalf = 128 * PK * 2;            // one half tile: 128 rows x 128 bytes = 16 KB
+constexpr int kBuf = 4 * kHalf;                // one k-tile: [A0 | A1 | W0 | W1] = 64 KB
+constexpr int kLdsMain = 2 * kBuf;             // 128 KB
+constexpr int kEpiRow16 = 144, kEpiRow32 = 272;  // epilogue tile row strides (bytes): 16-byte aligned, bank-spread
+constexpr int kLdsEpi = 8 * 128 * kEpiRow16;   // 144 KB (mode 2: 8 x 64 x 272 = 136 KB)
+constexpr int kLds8 = kLdsEpi > kLdsMain ? kLdsEpi : kLdsMain;
+
+template <int N>
+__device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds8() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// VAR (A/B runs, CRS_GEMM8_VAR): 0 = the schedule described above; 1 = the W fragments of the wave tile's right half are read
+// in phase 1 instead of phase 0 (12 / 4 / 8 / 0 fragment reads per phase instead of 16 / 0 / 8 / 0) and every half tile is
+// issued one phase later (two half tiles in flight behind vmcnt(4)); 2 = VAR 0 without s_setprio; 3 = VAR 0 without the
+// half-phase stagger of the row groups.
+template <int MODE, int VAR>
+__global__ __launch_bounds__(kP8Threads, 2) void gemm8_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                             const float* __restrict__ bias, const float* __restrict__ residual,
+                                                             void* __restrict__ out, int M, int N, int K, int Ksplit) {
+  // MODE 3 (split-K): workgroup (x, y) contracts columns [y Ksplit, (y + 1) Ksplit) of K and leaves its fp32 partial tile in
+  // slab y of out[gridDim.y][M][N]; bias / residual / LayerNorm belong to the kernel that sums the slabs (enc_misc.hip).
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) char sm8[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ncb = N / PN;
+  const int wid = xcd_chunked_id((int)blockIdx.x, (int)gridDim.x);   // column blocks of a row block meet in one L2
+  const int m0 = (wid / ncb) * PM, n0 = (wid % ncb) * PN;
+
+  // ---- transfers.  LDS position P = j * 512 + tid (16-byte units) of a half tile = (row P >> 3, slot P & 7) receives
+  // source chunk slot ^ ((row >> 1) & 7) of that row; the same (row, chunk) pattern serves all four half tiles.
+  unsigned voff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int id = j * kP8Threads + tid, row = id >> 3, slot = id & 7;
+    voff[j] = (unsigned)row * (unsigned)K * 2u + (unsigned)((slot ^ ((row >> 1) & 7)) << 4);
+  }
+  const int kbeg = (MODE == 3) ? (int)blockIdx.y * Ksplit : 0;
+  const _Float16* a_half[2] = {uniform_ptr(A + (size_t)m0 * K + kbeg), uniform_ptr(A + (size_t)(m0 + 128) * K + kbeg)};
+  const _Float16* w_half[2] = {uniform_ptr(W + (size_t)n0 * K + kbeg), uniform_ptr(W + (size_t)(n0 + 128) * K + kbeg)};
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)sm8 + (unsigned)wave * 1024u);
+  // half: 0 / 1 = A rows 0-127 / 128-255, 2 / 3 = W rows 0-127 / 128-255; kt = k-tile index
+  auto issue = [&](int buf, int half, int kt) {
+    const _Float16* base = (half < 2 ? a_half[half] : w_half[half - 2]) + (size_t)kt * PK;
+    const unsigned d = lds0 + (unsigned)(buf * kBuf + half * kHalf);
+    lds_dma16(d, voff[0], base);
+    lds_dma16(d + 8192u, voff[1], base);
+  };
+
+  // ---- fragment addresses: lane (r = lane & 15, h = lane >> 4) reads row r of a 16-row tile, 16-byte chunk 4 s + h
+  const int r = lane & 15, h = lane >> 4;
+  const int sw = (r >> 1) & 7;
+  const int lo0 = r * 128 + ((h ^ sw) << 4);            // k sub-step 0
+  const int lo1 = r * 128 + (((4 + h) ^ sw) << 4);      // k sub-step 1
+  const char* a_base = sm8 + wm * kHalf;                                            // this row group's A half
+  const char* w_base = sm8 + (2 + (wn >> 1)) * kHalf + (wn & 1) * 64 * 128;         // this wave's 64 W rows
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 af[4][2], bf[4][2];
+
+  const int nk = ((MODE == 3) ? Ksplit : K) / PK;   // even (a multiple of 128 columns: the dispatch checks)
+  // prologue: k-tile 0 whole, k-tile 1 up to its A half 0 (the loop's phase 0 issues A half 1 of the next k-tile)
+  issue(0, 2, 0); issue(0, 3, 0); issue(0, 0, 0); issue(0, 1, 0);
+  issue(1, 2, 1); issue(1, 3, 1);
+  if (VAR == 1) { wait_vm8<4>(); } else { issue(1, 0, 1); wait_vm8<6>(); }
+  __builtin_amdgcn_s_barrier();
+  if (VAR != 3 && wm == 1) __builtin_amdgcn_s_barrier();   // the row groups run one barrier apart from here on
+
+#define CRS_MFMA_QUAD(RT0, CT0)                                                                                         \
+  if (VAR != 2) __builtin_amdgcn_s_setprio(1);                                                                                      \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                      \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                      \
+      acc[(RT0) + i_][(CT0) + j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[(CT0) + j_][s_], af[i_][s_], acc[(RT0) + i_][(CT0) + j_], 0, 0, 0); \
+  if (VAR != 2) __builtin_amdgcn_s_setprio(0);
+
+  auto ktile = [&](int t, const int b) {
+    const char* ab = a_base + b * kBuf;
+    const char* wb = w_base + b * kBuf;
+    // ---- phase 0: A rows 0-63 of the wave tile, its W rows (VAR 1: the left half of them); quadrant (0, 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *reinterpret_cast<const f16x8*>(ab + i * 2048 + lo0);
+      af[i][1] = *reinterpret_cast<const f16x8*>(ab + i * 2048 + lo1);
+    }
+#pragma unroll
+    for (int j = 0; j < (VAR == 1 ? 2 : 4); ++j) {
+      bf[j][0] = *reinterpret_cast<const f16x8*>(wb + j * 2048 + lo0);
+      bf[j][1] = *reinterpret_cast<const f16x8*>(wb + j * 2048 + lo1);
+    }
+    if (t + 1 < nk) issue(b ^ 1, VAR == 1 ? 0 : 1, t + 1);
+    wait_lds8();
+    __builtin_amdgcn_s_barrier();
+    CRS_MFMA_QUAD(0, 0)
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: quadrant (0, 1)
+    if (VAR == 1) {
+#pragma unroll
+      for (int j = 2; j < 4; ++j) {
+        bf[j][0] = *reinterpret_cast<const f16x8*>(wb + j * 2048 + lo0);
+        bf[j][1] = *reinterpret_cast<const f16x8*>(wb + j * 2048 + lo1);
+      }
+      if (t + 1 < nk) issue(b ^ 1, 1, t + 1);
+      wait_lds8();
+    } else {
+      if (t + 2 < nk) issue(b, 2, t + 2);
+    }
+    __builtin_amdgcn_s_barrier();
+    CRS_MFMA_QUAD(0, 2)
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: A rows 64-127; quadrant (1, 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *reinterpret_cast<const f16x8*>(ab + (4 + i) * 2048 + lo0);
+      af[i][1] = *reinterpret_cast<const f16x8*>(ab + (4 + i) * 2048 + lo1);
+    }
+    if (t + 2 < nk) issue(b, VAR == 1 ? 2 : 3, t + 2);
+    wait_lds8();
+    __builtin_amdgcn_s_barrier();
+    CRS_MFMA_QUAD(4, 2)
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: quadrant (1, 0); k-tile t + 1 must have landed (the younger half tiles may stay in flight)
+    if (t + 2 < nk) { issue(b, VAR == 1 ? 3 : 0, t + 2); if (VAR == 1) wait_vm8<4>(); else wait_vm8<6>(); } else { wait_vm8<0>(); }
+    __builtin_amdgcn_s_barrier();
+    CRS_MFMA_QUAD(4, 0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int t = 0; t < nk; t += 2) {
+    ktile(t, 0);
+    ktile(t + 1, 1);
+  }
+#undef CRS_MFMA_QUAD
+  if (VAR != 3 && wm == 0) __builtin_amdgcn_s_barrier();   // re-align the row groups
+  __builtin_amdgcn_s_barrier();                // every fragment read is done: the buffers become the waves' output tiles
+
+  // ---- epilogue.  Lane (c = lane & 15, q = lane >> 4) holds, per accumulator tile (rt, ct), token row rt * 16 + c and the
+  // four consecutive output columns ct * 16 + 4 q .. + 3 (the product is formed transposed for exactly this).
+  const int c = lane & 15, q = lane >> 4;
+  f32x4 bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bv[j] = (bias && MODE != 3) ? *reinterpret_cast<const f32x4*>(bias + n0 + wn * 64 + j * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int row_g0 = m0 + wm * 128, col_g0 = n0 + wn * 64;
+  if (MODE < 2) {
+    char* my = sm8 + wave * (128 * kEpiRow16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = acc[i][j] + bv[j];
+        gelu_f32x2 x0 = {v[0], v[1]}, x1 = {v[2], v[3]};
+        if (MODE == 1) { x0 = gelu_erf2(x0); x1 = gelu_erf2(x1); }
+        const f16x4 hv = {(_Float16)x0[0], (_Float16)x0[1], (_Float16)x1[0], (_Float16)x1[1]};
+        *reinterpret_cast<f16x4*>(my + (i * 16 + c) * kEpiRow16 + (j * 16 + 4 * q) * 2) = hv;
+      }
+    __builtin_amdgcn_wave_barrier();
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int lrow = it * 8 + (lane >> 3), ch = lane & 7;
+      const f16x8 v = *reinterpret_cast<const f16x8*>(my + lrow * kEpiRow16 + ch * 16);
+      *reinterpret_cast<f16x8*>(o + (size_t)(row_g0 + lrow) * N + col_g0 + ch * 8) = v;
+    }
+  } else {
+    char* my = sm8 + wave * (64 * kEpiRow32);
+    float* o = reinterpret_cast<float*>(out) + (MODE == 3 ? (size_t)blockIdx.y * M * N : (size_t)0);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {          // 64 token rows at a time (a 64 x 64 fp32 tile = 17 KB per wave)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(my + (i * 16 + c) * kEpiRow32 + (j * 16 + 4 * q) * 4) = acc[hh * 4 + i][j] + bv[j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int lrow = it * 4 + (lane >> 4), ch = lane & 15;
+        f32x4 v = *reinterpret_cast<const f32x4*>(my + lrow * kEpiRow32 + ch * 16);
+        const size_t at = (size_t)(row_g0 + hh * 64 + lrow) * N + col_g0 + ch * 4;
+        if (MODE == 2) v += *reinterpret_cast<const f32x4*>(residual + at);
+        *reinterpret_cast<f32x4*>(o + at) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int MODE, int VAR>
+int launch8v(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k,
+             int splits, hipStream_t stream) {
+  static bool done = false;
+  auto kernel = &gemm8_kernel<MODE, VAR>;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  const int grid = (n / PN) * (m / PM);
+  hipLaunchKernelGGL(kernel, dim3(grid, MODE == 3 ? splits : 1), dim3(kP8Threads), kLds8, stream, a, w, bias, residual, out, m, n, k,
+                     k / (MODE == 3 ? splits : 1));
+  return (int)hipGetLastError();
+}
+
+template <int MODE>
+int launch8(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k,
+            int splits, hipStream_t stream) {
+  static int var = -1;
+  if (var < 0) { const char* e = getenv("CRS_GEMM8_VAR"); var = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0; }
+  switch (var) {
+    case 1: return launch8v<MODE, 1>(a, w, bias, residual, out, m, n, k, splits, stream);
+    case 2: return launch8v<MODE, 2>(a, w, bias, residual, out, m, n, k, splits, stream);
+    case 3: return launch8v<MODE, 3>(a, w, bias, residual, out, m, n, k, splits, stream);
+    default: return launch8v<MODE, 0>(a, w, bias, residual, out, m, n, k, splits, stream);
+  }
+}
+
+}  // namespace
+
+// Shapes the phase-scheduled kernel takes: whole 256 x 256 tiles, K a multiple of 128 and >= 256 (two k-tiles in the
+// prologue), 16-byte aligned rows.  CRS_GEMM8=0 disables it (A/B runs); CRS_GEMM8_MIN_WGS moves the lower limit.
+bool gemm8_applies(int m, int n, int k, int mode) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CRS_GEMM8"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || m % PM || n % PN || k % 128 || k < 256) return false;
+  static long min_wgs = -1;
+  if (min_wgs < 0) { const char* e = getenv("CRS_GEMM8_MIN_WGS"); min_wgs = e ? atol(e) : 128; }
+  return (long)(m / PM) * (n / PN) >= min_wgs;
+}
+
+int gemm8_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k, int mode,
+                 hipStream_t stream) {
+  switch (mode) {
+    case 0: return launch8<0>(a, w, bias, residual, out, m, n, k, 1, stream);
+    case 1: return launch8<1>(a, w, bias, residual, out, m, n, k, 1, stream);
+    case 2: return launch8<2>(a, w, bias, residual, out, m, n, k, 1, stream);
+    default: return -1;
+  }
+}
+
+// Split-K form for projections whose output has too few 256 x 256 tiles to fill the chip (bge-base's N = 768 at a few
+// thousand tokens): the number of K slabs (0 = not applicable) such that tiles x slabs >= 128 workgroups, every slab a
+// multiple of 128 columns and >= 256; the LayerNorm kernel that follows sums the fp32 slabs (it is instantiated for
+// 2 / 3 / 4 / 6 / 8 of them).
+int gemm8_splitk(int m, int n, int k) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CRS_GEMM8"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || m % PM || n % PN || m < 2048) return 0;
+  const long tiles = (long)(m / PM) * (n / PN);
+  if (tiles >= 128) return 0;
+  const int cand[5] = {2, 3, 4, 6, 8};
+  for (int s : cand)
+    if (k % s == 0 && (k / s) % 128 == 0 && k / s >= 256 && tiles * s >= 128) return s;
+  return 0;
+}
+
+int gemm8_splitk_launch(const _Float16* a, const _Float16* w, float* partials, int m, int n, int k, int splits, hipStream_t stream) {
+  return launch8<3>(a, w, nullptr, nullptr, partials, m, n, k, splits, stream);
+}
+
+}  // namespace crs

@@ -32,7 +32,9 @@ def _cos(a, b):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (200, 384, 384), (1024, 1152, 384), (77, 192, 256), (300, 384, 1536),
                                    (4100, 1152, 384), (2049, 200, 128), (8192, 1536, 384), (3000, 384, 512), (5000, 96, 256),
-                                   (4100, 2304, 768), (2049, 520, 768), (600, 3072, 768)])
+                                   (4100, 2304, 768), (2049, 520, 768), (600, 3072, 768),
+                                   # whole 256 x 256 tiles, >= 128 of them: the phase-scheduled kernel (enc_gemm8.hip), shortest and long K
+                                   (8192, 1024, 768), (4096, 2304, 256), (4096, 2048, 3072)])
 def test_gemm_vs_torch_fp32(cuda, mode, m, n, k):
     import torch
     from rag._encoder import gemm_f16
@@ -60,6 +62,9 @@ def test_gemm_vs_torch_fp32(cuda, mode, m, n, k):
     # index-build regime (> 4096 tokens: tiled / streaming GEMMs at K = 768 / 3072, transposed attention over 8 key blocks)
     ("minilm-4x256", er.MINILM_L6, 31, 4, 256), ("bge-2x512", er.BGE_BASE, 32, 2, 512), ("bge-10x512", er.BGE_BASE, 33, 10, 512),
     ("minilm-20x256", er.MINILM_L6, 34, 20, 256),
+    # C3's query batch: 4096 tokens of bge-base -- QKV / FFN-up on the phase-scheduled 256 x 256 kernel, the two N = 768
+    # projections on its split-K form (3 fp32 slabs summed by the LayerNorm kernel)
+    ("bge-256x16", er.BGE_BASE, 35, 256, 16),
 ])
 def test_encoder_matches_oracle(cuda, name, cfg, seed, batch, seq):
     import torch
