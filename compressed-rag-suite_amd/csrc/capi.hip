@@ -317,6 +317,14 @@ int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_d
   return e ? hip_fail((hipError_t)e, "rescore launch") : CRS_OK;
 }
 
+int crs_score_rows_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows, int64_t id_base, int k,
+                       const int64_t* ids_dev, float* scores_dev, void* stream) {
+  if (nq <= 0 || dim <= 0 || k <= 0 || n_rows <= 0) return fail(CRS_EINVAL, "bad sizes");
+  if (!q32_dev || !shadow_dev || !ids_dev || !scores_dev) return fail(CRS_EINVAL, "null pointer");
+  const int e = crs::score_rows_launch(q32_dev, nq, dim, shadow_dev, n_rows, id_base, k, ids_dev, scores_dev, (hipStream_t)stream);
+  return e ? hip_fail((hipError_t)e, "score_rows launch") : CRS_OK;
+}
+
 int crs_refine_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
                    int64_t id_base, const int64_t* cand_ids_dev, int k_in, int k_out,
                    float* out_scores_dev, int64_t* out_ids_dev, void* stream) {

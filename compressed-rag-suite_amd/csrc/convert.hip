@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void rescore_dot_kernel(const float* __restric
     return;
   }
   const int64_t row = id - id_base;
-  if (row < 0 || row >= n_rows) return;  // foreign shard: leave untouched
+  if (row < 0 || row >= n_rows) return;  // foreign shard: leave untouched (the caller pre-fills)
   const float* a = q32 + (size_t)qi * dim;
   const float* b = shadow + (size_t)row * dim;
   float acc = 0.f;
@@ -208,6 +208,16 @@ int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_
 int queries_to_f16_launch(const float* q, int nq, int dim, int pdim, _Float16* out,
                           hipStream_t stream) {
   return slab_append_launch(q, nq, dim, pdim, 0, out, nullptr, nullptr, 0, nullptr, stream);
+}
+
+// fp32 scores of arbitrary candidate lists (any k): out[e] = <q32[e / k], shadow[ids[e] - id_base]>, -inf for ids < 0
+int score_rows_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows, int64_t id_base, int k, const int64_t* ids,
+                      float* scores, hipStream_t stream) {
+  const int64_t e = (int64_t)nq * k;
+  if (e <= 0) return 0;
+  hipLaunchKernelGGL(rescore_dot_kernel, dim3((unsigned)((e + 3) / 4)), dim3(256), 0, stream, q32, nq, dim, shadow, n_rows, id_base, k,
+                     scores, ids);
+  return (int)hipGetLastError();
 }
 
 int rescore_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows,

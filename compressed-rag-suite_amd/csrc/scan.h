@@ -75,6 +75,8 @@ int refine_f32_launch(const float* q32, int nq, int dim, const float* shadow, in
 int slab_append_launch(const float* emb, int64_t n, int dim, int pdim, int slab_type, void* slab,
                        float* scales, float* shadow, int64_t row0, float* row_err_max, hipStream_t stream);
 int queries_to_f16_launch(const float* q, int nq, int dim, int pdim, _Float16* out, hipStream_t stream);
+int score_rows_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows, int64_t id_base, int k, const int64_t* ids,
+                      float* scores, hipStream_t stream);
 int rescore_launch(const float* q32, int nq, int dim, const float* shadow, int64_t n_rows,
                    int64_t id_base, int k, float* scores, int64_t* ids, hipStream_t stream);
 

@@ -26,8 +26,10 @@ constexpr float kNegInfR = -__builtin_huge_valf();
 // end are clamped and masked afterwards) so that the D/32 loads of a block are all in flight at once.
 constexpr int kRefThreads = 1024;
 
-template <int D>
-__global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __restrict__ q16, const _Float16* __restrict__ slab,
+// TH threads per workgroup: 1024 (16 waves x <= 128 registers) up to 768-element rows; 896 / 1024-element rows keep their
+// query fragments (D / 8 registers) in 8 waves x <= 256 registers instead of spilling
+template <int D, int TH>
+__global__ __launch_bounds__(TH) void refine_kernel(const _Float16* __restrict__ q16, const _Float16* __restrict__ slab,
                                                             int n_rows, const float* __restrict__ win_s,
                                                             const int64_t* __restrict__ win, int k, int tile_rows, int64_t id_base, float* __restrict__ out_s,
                                                             int64_t* __restrict__ out_i) {
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, kq = lane >> 4;
   if (tid == 0) cnt = 0;
-  for (int r = tid; r < k; r += kRefThreads) { out_s[(size_t)q * k + r] = kNegInfR; out_i[(size_t)q * k + r] = -1; }
+  for (int r = tid; r < k; r += TH) { out_s[(size_t)q * k + r] = kNegInfR; out_i[(size_t)q * k + r] = -1; }
 
   const int halves = tile_rows / 16;          // 16-row MFMA blocks per tile: 1, 2 or 4
   const int units = k * halves;               // <= 128
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
   for (int ks = 0; ks < kKs; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(qrow + ks * 32);
   __syncthreads();
 
-  for (int u = wave; u < units; u += kRefThreads / 64) {
+  for (int u = wave; u < units; u += TH / 64) {
     const int j = u / halves, hb = u % halves;
     const int64_t w = win[(size_t)q * k + j];
     const int first = (w < 0) ? 0 : ((int)w / tile_rows) * tile_rows + hb * 16;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_kernel(const _Float16* __r
   }
   __syncthreads();
   const int m = cnt;
-  for (int c = tid; c < m; c += kRefThreads) {   // rank by counting = output slot
+  for (int c = tid; c < m; c += TH) {   // rank by counting = output slot
     const float s = cs[c];
     const int id = ci[c];
     int rank = 0;
@@ -207,8 +209,8 @@ int refine_i8_launch(const _Float16* q16, int nq, int pdim, const void* slab, co
 int refine_launch(const _Float16* q16, int nq, int pdim, const _Float16* slab, int n_rows, const float* win_s,
                   const int64_t* win, int k, int tile_rows, int64_t id_base, float* out_s, int64_t* out_i, hipStream_t stream) {
   if (k > 64 || (tile_rows != 16 && tile_rows != 32 && tile_rows != 64) || k * tile_rows > 2048) return -1;
-#define CRS_REFINE(DD) hipLaunchKernelGGL((refine_kernel<DD>), dim3(nq), dim3(kRefThreads), 0, stream, q16, slab, n_rows, win_s, win, k, tile_rows, \
-                                         id_base, out_s, out_i)
+#define CRS_REFINE(DD) hipLaunchKernelGGL((refine_kernel<DD, (DD >= 896 ? 512 : 1024)>), dim3(nq), dim3(DD >= 896 ? 512 : 1024), 0, stream, q16, slab, \
+                                         n_rows, win_s, win, k, tile_rows, id_base, out_s, out_i)
   switch (pdim) {
     case 128: CRS_REFINE(128); break;
     case 256: CRS_REFINE(256); break;

@@ -265,8 +265,13 @@ int launch_tb_k(const ScanArgs& a, int slots, hipStream_t stream) {
     // waves per SIMD; 64 slots only for 256- / 384-element rows (they spill from 512 on).  10 M x 384, 64 queries, k = 17 / 32:
     // scan 2.36 / 2.13 ms on the threshold kernels -> 1.23 ms, whole search 2.09 / 2.16 -> 1.31 / 1.32.
     case 32: if constexpr (NW == 4) return launch_tb<D, TR, NW, 32>(a, stream); else return -1;
-    case 64: if constexpr (NW == 4 && (D == 256 || D == 384)) return launch_tb<D, TR, NW, 64>(a, stream); else return -1;
-    case 48: if constexpr (NW == 4 && D >= 512 && D <= 768) return launch_tb<D, TR, NW, 48>(a, stream); else return -1;   // k <= 48: the reference's 2 k = 40
+    // register budgets checked by tools/check_resources.py (no plan-selectable instantiation may touch scratch): 64 slots
+    // fit 256-element rows only (384: 20 bytes / lane of scratch), 56 / 48 slots 384-element rows, 48 slots 512 / 640, 40 slots
+    // (the reference's 2 k = 40 with rerank on) 768
+    case 64: if constexpr (NW == 4 && D == 256) return launch_tb<D, TR, NW, 64>(a, stream); else return -1;
+    case 56: if constexpr (NW == 4 && D == 384) return launch_tb<D, TR, NW, 56>(a, stream); else return -1;
+    case 48: if constexpr (NW == 4 && D >= 384 && D <= 640) return launch_tb<D, TR, NW, 48>(a, stream); else return -1;
+    case 40: if constexpr (NW == 4 && D == 768) return launch_tb<D, TR, NW, 40>(a, stream); else return -1;
     default: return -1;
   }
 }
@@ -303,8 +308,11 @@ int scan_tb_wg_per_cu(int pdim, int nw) {
 int scan_tb_long_chain_slots(int pdim, int nw, int k) {
   if (nw != 4 || k <= 16 || k > 64) return 0;
   if (k <= 32) return 32;
-  if (pdim == 256 || pdim == 384) return 64;
-  return (k <= 48 && pdim >= 512 && pdim <= 768) ? 48 : 0;     // 512 .. 768-element rows: 48 slots still fit (64 spill)
+  if (pdim == 256) return 64;
+  if (pdim == 384) return k <= 48 ? 48 : (k <= 56 ? 56 : 0);
+  if (pdim == 512 || pdim == 640) return k <= 48 ? 48 : 0;
+  if (pdim == 768) return k <= 40 ? 40 : 0;
+  return 0;
 }
 
 // slots = 0: dump mode (kp = tiles per stream); else chain mode with that many slots (kp = slots)

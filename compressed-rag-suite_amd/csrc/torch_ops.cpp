@@ -149,6 +149,19 @@ void refine_f32_out(const Tensor& q32, const Tensor& shadow, int64_t n_rows, int
                     out_ids.data_ptr<int64_t>(), cur_stream(q32)), "crs::refine_f32");
 }
 
+void score_rows_f32_out(const Tensor& q32, const Tensor& shadow, int64_t n_rows, int64_t id_base, const Tensor& ids, Tensor scores) {
+  want(q32, at::kFloat, "q32");
+  want(shadow, at::kFloat, "shadow");
+  want(ids, at::kLong, "ids");
+  want(scores, at::kFloat, "scores");
+  TORCH_CHECK(q32.dim() == 2 && shadow.dim() == 2 && ids.dim() == 2 && shadow.size(1) == q32.size(1) && ids.size(0) == q32.size(0) &&
+                  scores.sizes() == ids.sizes() && n_rows <= shadow.size(0), "q32 [nq, dim], shadow [>= n_rows, dim], ids / scores [nq, k]");
+  same_device(q32, {&shadow, &ids, &scores}, "crs::score_rows_f32");
+  c10::hip::HIPGuardMasqueradingAsCUDA g(q32.device());
+  ok(crs_score_rows_f32(q32.data_ptr<float>(), (int)q32.size(0), (int)q32.size(1), shadow.data_ptr<float>(), n_rows, id_base, (int)ids.size(1),
+                        ids.data_ptr<int64_t>(), scores.data_ptr<float>(), cur_stream(q32)), "crs::score_rows_f32");
+}
+
 // ---- exactness certificate + escalation (include/crs_hip.h, csrc/exact.hip) --------------------------------------------------
 void refine_f32_cert_out(const Tensor& q32, const Tensor& q16, const Tensor& shadow, int64_t n_rows, int64_t id_base,
                          const Tensor& cand_ids, const Tensor& cand_scores, int64_t k_out, double row_err_max, int64_t slab_type,
@@ -298,7 +311,7 @@ void encoder_forward(const Tensor& ids, const Tensor& lens, at::TensorList weigh
 }  // namespace
 
 TORCH_LIBRARY(crs, m) {
-  m.def("slab_append(Tensor emb, Tensor(a!) slab, Tensor(b!)? scales, Tensor(c!)? shadow, int row0, Tensor(d!)? row_err) -> ()");
+  m.def("slab_append(Tensor emb, Tensor(a!) slab, Tensor(b!)? scales, Tensor(c!)? shadow, int row0, Tensor(d!)? row_err=None) -> ()");
   m.def("queries_to_f16(Tensor q32, Tensor(a!) out16, int slab_type) -> ()");
   m.def("cosine_topk(Tensor q16, Tensor slab, Tensor? scales, int n_rows, int dim, int k, int id_base) -> (Tensor, Tensor)");
   m.def("cosine_topk_out(Tensor q16, Tensor slab, Tensor? scales, int n_rows, int dim, int k, int id_base, Tensor(a!) workspace, "
@@ -306,6 +319,7 @@ TORCH_LIBRARY(crs, m) {
   m.def("refine_f32(Tensor q32, Tensor shadow, int n_rows, int id_base, Tensor cand_ids, int k_out) -> (Tensor, Tensor)");
   m.def("refine_f32_out(Tensor q32, Tensor shadow, int n_rows, int id_base, Tensor cand_ids, int k_out, Tensor(a!) out_scores, "
         "Tensor(b!) out_ids) -> ()");
+  m.def("score_rows_f32_out(Tensor q32, Tensor shadow, int n_rows, int id_base, Tensor ids, Tensor(a!) scores) -> ()");
   m.def("refine_f32_cert_out(Tensor q32, Tensor q16, Tensor shadow, int n_rows, int id_base, Tensor cand_ids, Tensor cand_scores, int k_out, "
         "float row_err_max, int slab_type, Tensor(a!) out_scores, Tensor(b!) out_ids, Tensor(c!) status, Tensor(d!) exact_ws, int cap) -> ()");
   m.def("escalate_exact(Tensor q32, Tensor q16, Tensor slab, Tensor? scales, Tensor shadow, int n_rows, int id_base, int k_out, "
@@ -324,6 +338,7 @@ TORCH_LIBRARY_IMPL(crs, CUDA, m) {   // the HIP backend of torch-ROCm dispatches
   m.impl("cosine_topk_out", &cosine_topk_out);
   m.impl("refine_f32", &refine_f32);
   m.impl("refine_f32_out", &refine_f32_out);
+  m.impl("score_rows_f32_out", &score_rows_f32_out);
   m.impl("refine_f32_cert_out", &refine_f32_cert_out);
   m.impl("escalate_exact", &escalate_exact);
   m.impl("merge_topk", &merge_topk);

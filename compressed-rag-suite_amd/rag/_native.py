@@ -39,6 +39,7 @@ _SIGNATURES = {
                                c_void_p]),
     "crs_rescore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                 c_void_p, c_void_p]),
+    "crs_score_rows_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "crs_refine_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int,
                                c_void_p, c_void_p, c_void_p]),
     "crs_exact_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -210,6 +211,15 @@ def rescore_f32(q32, shadow, n_rows: int, id_base: int, scores, ids) -> None:
     k = scores.shape[1]
     check(load().crs_rescore_f32(_ptr(q32), nq, dim, _ptr(shadow), n_rows, id_base, k, _ptr(scores),
                                  _ptr(ids), _stream_ptr()))
+
+
+def score_rows_f32(q32, shadow, n_rows: int, id_base: int, ids):
+    """fp32 scores of candidate lists of any length: ids int64 [nq, k] -> fp32 [nq, k] (-inf where ids < 0)."""
+    import torch
+    scores = torch.full(ids.shape, float("-inf"), dtype=torch.float32, device=q32.device)
+    with _translate():
+        ops().score_rows_f32_out(q32, shadow, int(n_rows), int(id_base), ids.contiguous(), scores)
+    return scores
 
 
 def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out_scores=None, out_ids=None):

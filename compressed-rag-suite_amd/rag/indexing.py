@@ -190,6 +190,93 @@ class SlabCollection:
     def count(self) -> int:
         return len(self.ids)
 
+    # -- metadata filters: value -> rows, built once and extended as rows arrive (the per-query loop over all metadatas is gone)
+    def _inverted(self):
+        inv = self.__dict__.setdefault("_inv", {})
+        done = self.__dict__.get("_inv_rows", 0)
+        for row in range(done, len(self.metadatas)):
+            for key, val in self.metadatas[row].items():
+                try:
+                    inv.setdefault(key, {}).setdefault(val, []).append(row)
+                except TypeError:           # unhashable value: never equal to a scalar filter value
+                    pass
+        self.__dict__["_inv_rows"] = len(self.metadatas)
+        return inv
+
+    def _where_rows(self, where: dict, n: int):
+        """Rows passing a ChromaDB `where` document: {key: value | {op: value}} (AND over keys), {"$and": [...]},
+        {"$or": [...]}; ops $eq $ne $in $nin $gt $gte $lt $lte (chromadb 1.3.0's documented operators; the reference only
+        forwards the dict).  Values are looked up in the inverted index: the cost follows the DISTINCT values of a key."""
+        every = lambda: np.arange(n, dtype=np.int64)                                          # noqa: E731
+        none = lambda: np.zeros(0, dtype=np.int64)                                            # noqa: E731
+        rows_of = lambda col, v: np.asarray(col.get(v, []), dtype=np.int64)                   # noqa: E731
+        out = None
+        for key, want in where.items():
+            if key in ("$and", "$or"):
+                parts = [self._where_rows(w, n) for w in want]
+                if key == "$and":
+                    hit = every()
+                    for p_ in parts:
+                        hit = np.intersect1d(hit, p_, assume_unique=True)
+                else:
+                    hit = np.unique(np.concatenate(parts)) if parts else none()
+            else:
+                col = self._inverted().get(key, {})
+                op, val = ("$eq", want)
+                if isinstance(want, dict):
+                    (op, val), = want.items()
+                try:
+                    if op in ("$eq", "$ne"):
+                        if val is None:       # meta.get(key) == None: the rows WITHOUT the key
+                            have = [np.asarray(v, dtype=np.int64) for v in col.values()]
+                            eq = np.setdiff1d(every(), np.concatenate(have) if have else none())
+                        else:
+                            eq = rows_of(col, val)
+                        hit = eq if op == "$eq" else np.setdiff1d(every(), eq, assume_unique=True)
+                    elif op in ("$in", "$nin") and isinstance(val, (list, tuple)):
+                        parts = [rows_of(col, v) for v in val]
+                        inn = np.unique(np.concatenate(parts)) if parts else none()
+                        hit = inn if op == "$in" else np.setdiff1d(every(), inn, assume_unique=True)
+                    elif op in ("$gt", "$gte", "$lt", "$lte") and isinstance(val, (int, float)) and not isinstance(val, bool):
+                        cmp = {"$gt": lambda x: x > val, "$gte": lambda x: x >= val, "$lt": lambda x: x < val, "$lte": lambda x: x <= val}[op]
+                        parts = [np.asarray(r, dtype=np.int64) for v, r in col.items()
+                                 if isinstance(v, (int, float)) and not isinstance(v, bool) and cmp(v)]
+                        hit = np.sort(np.concatenate(parts)) if parts else none()
+                    else:
+                        hit = none()
+                except TypeError:             # unhashable filter value: nothing can equal it
+                    hit = every() if op in ("$ne", "$nin") else none()
+            out = hit if out is None else np.intersect1d(out, hit, assume_unique=True)
+        return every() if out is None else out
+
+    def _doc_rows(self, cond: dict, base):
+        rows = base
+        for op, val in cond.items():
+            if op == "$contains":
+                rows = [r for r in rows if val in self.documents[r]]
+            elif op == "$not_contains":
+                rows = [r for r in rows if val not in self.documents[r]]
+            elif op == "$and":
+                for c in val:
+                    rows = self._doc_rows(c, rows)
+            elif op == "$or":
+                keep = set()
+                for c in val:
+                    keep.update(self._doc_rows(c, rows))
+                rows = [r for r in rows if r in keep]
+        return rows
+
+    def rows_matching(self, where: Optional[dict], where_document: Optional[dict]):
+        """Sidecar rows (ascending numpy int64) that pass the filters the reference forwards to ChromaDB
+        (rag/indexing.py:129-130,174).  None = no filter."""
+        if not where and not where_document:
+            return None
+        n = len(self.ids)
+        rows = self._where_rows(where, n) if where else np.arange(n, dtype=np.int64)
+        if where_document:                    # substring tests have no index: one pass over the surviving documents
+            rows = np.asarray(self._doc_rows(where_document, rows.tolist()), dtype=np.int64)
+        return rows
+
 
 class VectorStore:
     """Vector store on an HBM slab.  Handles storage, indexing and exact similarity search."""
@@ -221,6 +308,9 @@ class VectorStore:
         if self.sharded and self.persist_directory:
             raise NotImplementedError("persist_directory is not supported with sharded=True (each rank holds only its rows); "
                                       "use num_gpus for a persisted multi-GPU store")
+        self._filters = {}      # filter key -> {"n": rows when built, "rows": allowed sidecar rows, "shards": {g: compacted sub-slab}}
+        self._persisted_rows = None   # rows the append-only files hold (None: nothing / legacy format on disk)
+        self._docs_bytes = 0          # length of the sidecar file the header vouches for
         self.client = self  # the reference keeps a chromadb client here; nothing else reads it
         self.collection: Optional[SlabCollection] = None
         self._wire = {}     # (nq, k) -> WireBlock (SPMD exchange buffers)
@@ -251,29 +341,87 @@ class VectorStore:
     def _new_collection(self) -> SlabCollection:
         return SlabCollection(self.collection_name, self.index_dtype, self.refine_fp32, self._torch_devices())
 
+    # -- persistence (the PersistentClient analogue, reference rag/indexing.py:32-34): APPEND-ONLY files, so that an add
+    # costs O(batch), not O(index):
+    #     <name>.meta.json    header {format, n, dim, pdim, index_dtype, shadow, row_err_max}; rewritten (tmp + rename) LAST
+    #     <name>.slab.bin     rows [n, pdim] fp16 | int8, raw little-endian, in sidecar order
+    #     <name>.scales.bin   fp32 [n]            (int8)
+    #     <name>.shadow.bin   fp32 [n, dim]       (refine_fp32)
+    #     <name>.docs.jsonl   one {"id", "document", "metadata"} line per row
+    # The header's n is the truth: bytes or lines past it (a crash between the appends and the header) are ignored and
+    # overwritten by the next add; files SHORTER than the header says mean corruption and raise.  The round-2 format
+    # (<name>.slab.npz + <name>.docs.json, rewritten whole on every add) is still read.
     def _persist_paths(self):
         base = os.path.join(self.persist_directory, self.collection_name)
-        return base + ".slab.npz", base + ".docs.json"
+        return {k: base + ext for k, ext in (("meta", ".meta.json"), ("slab", ".slab.bin"), ("scales", ".scales.bin"),
+                                             ("shadow", ".shadow.bin"), ("docs", ".docs.jsonl"),
+                                             ("legacy_slab", ".slab.npz"), ("legacy_docs", ".docs.json"))}
+
+    def _load_rows_into(self, col, n, dim, rows, refine, row_err):
+        import torch
+        for g, (lo, hi) in enumerate(_shard.batch_slices(n, len(col.shards))):
+            sh = col.shards[g]
+            sh.reserve(hi - lo, dim)
+            if hi > lo:
+                sh.slab[: hi - lo].copy_(torch.from_numpy(np.ascontiguousarray(rows["slab"][lo:hi])))
+                if rows["scales"] is not None:
+                    sh.scales[: hi - lo].copy_(torch.from_numpy(np.ascontiguousarray(rows["scales"][lo:hi])))
+                if refine:
+                    sh.shadow[: hi - lo].copy_(torch.from_numpy(np.ascontiguousarray(rows["shadow"][lo:hi])))
+                sh.rows_global[: hi - lo] = torch.arange(lo, hi, device=sh.device)
+            sh.n = hi - lo
+            sh.identity = (lo == 0)
+            sh.row_err.fill_(row_err)
 
     def _initialize_collection(self):
         """Re-open a persisted collection if there is one (reference: get_collection, :46-55)."""
         if not self.persist_directory:
             logger.info("Using in-memory (HBM) storage")
             return
-        slab_path, docs_path = self._persist_paths()
-        if not (os.path.exists(slab_path) and os.path.exists(docs_path)):
+        paths = self._persist_paths()
+        legacy = not os.path.exists(paths["meta"])
+        if legacy and not (os.path.exists(paths["legacy_slab"]) and os.path.exists(paths["legacy_docs"])):
             logger.info(f"Collection '{self.collection_name}' will be created on first add")
             return
-        import torch
         try:
-            z = np.load(slab_path, allow_pickle=False)
-            with open(docs_path) as fh:
-                side = json.load(fh)
-            n, dim, dtype = int(z["n"]), int(z["dim"]), str(z["index_dtype"])
-            rows = {"slab": z["slab"], "scales": z["scales"] if dtype == "int8" else None,
-                    "shadow": z["shadow"] if "shadow" in z.files else None}
-            if len(side["ids"]) != n or rows["slab"].shape[0] != n:
-                raise ValueError(f"slab holds {rows['slab'].shape[0]} rows, sidecar {len(side['ids'])}, header {n}")
+            if legacy:
+                z = np.load(paths["legacy_slab"], allow_pickle=False)
+                with open(paths["legacy_docs"]) as fh:
+                    side = json.load(fh)
+                n, dim, dtype = int(z["n"]), int(z["dim"]), str(z["index_dtype"])
+                rows = {"slab": z["slab"], "scales": z["scales"] if dtype == "int8" else None,
+                        "shadow": z["shadow"] if "shadow" in z.files else None}
+                row_err = float(z["row_err_max"]) if "row_err_max" in z.files else None
+                ids, docs, metas = side["ids"], side["documents"], side["metadatas"]
+                if len(ids) != n or rows["slab"].shape[0] != n:
+                    raise ValueError(f"slab holds {rows['slab'].shape[0]} rows, sidecar {len(ids)}, header {n}")
+            else:
+                with open(paths["meta"]) as fh:
+                    meta = json.load(fh)
+                n, dim, pdim, dtype = int(meta["n"]), int(meta["dim"]), int(meta["pdim"]), str(meta["index_dtype"])
+                elem = np.int8 if dtype == "int8" else np.float16
+
+                def raw(key, np_dtype, width):
+                    need = n * width * np.dtype(np_dtype).itemsize
+                    if os.path.getsize(paths[key]) < need:
+                        raise ValueError(f"{os.path.basename(paths[key])} holds fewer than the header's {n} rows")
+                    return np.fromfile(paths[key], dtype=np_dtype, count=n * width).reshape(n, width) if n else np.zeros((0, width), np_dtype)
+
+                rows = {"slab": raw("slab", elem, pdim),
+                        "scales": raw("scales", np.float32, 1).reshape(-1) if dtype == "int8" else None,
+                        "shadow": raw("shadow", np.float32, dim) if meta.get("shadow") else None}
+                row_err = meta.get("row_err_max")
+                ids, docs, metas = [], [], []
+                with open(paths["docs"], "rb") as fh:
+                    blob = fh.read(int(meta["docs_bytes"]))
+                if len(blob) < int(meta["docs_bytes"]):
+                    raise ValueError("sidecar shorter than the header says")
+                for line in blob.decode("utf-8").splitlines():
+                    rec = json.loads(line)
+                    ids.append(rec["id"]); docs.append(rec["document"]); metas.append(rec["metadata"])
+                if len(ids) != n:
+                    raise ValueError(f"sidecar holds {len(ids)} rows, header {n}")
+                self._docs_bytes = int(meta["docs_bytes"])
         except Exception as e:
             # a truncated / foreign file must not silently become an empty store that the next add overwrites
             raise RuntimeError(f"persisted collection '{self.collection_name}' under {self.persist_directory} is unreadable: {e}") from e
@@ -282,52 +430,83 @@ class VectorStore:
         if self.refine_fp32 and not refine:
             logger.warning("persisted collection has no fp32 shadow; refine_fp32 disabled")
         col = SlabCollection(self.collection_name, dtype, refine, self._torch_devices())
-        for g, (lo, hi) in enumerate(_shard.batch_slices(n, len(col.shards))):
-            sh = col.shards[g]
-            sh.reserve(hi - lo, dim)
-            if hi > lo:
-                sh.slab[: hi - lo].copy_(torch.from_numpy(rows["slab"][lo:hi]))
-                if rows["scales"] is not None:
-                    sh.scales[: hi - lo].copy_(torch.from_numpy(rows["scales"][lo:hi]))
-                if refine:
-                    sh.shadow[: hi - lo].copy_(torch.from_numpy(rows["shadow"][lo:hi]))
-                sh.rows_global[: hi - lo] = torch.arange(lo, hi, device=sh.device)
-            sh.n = hi - lo
-            sh.identity = (lo == 0)
-            # the certificate's row term: the persisted maximum, or the analytic worst case for files written before it existed
-            sh.row_err.fill_(float(z["row_err_max"]) if "row_err_max" in z.files
-                             else nat.exact_row_error_bound(dim, nat.SLAB_I8 if dtype == "int8" else nat.SLAB_F16))
-        col.ids, col.documents, col.metadatas = side["ids"], side["documents"], side["metadatas"]
+        # the certificate's row term: the persisted maximum, or the analytic worst case for files written before it existed
+        if row_err is None:
+            row_err = nat.exact_row_error_bound(dim, nat.SLAB_I8 if dtype == "int8" else nat.SLAB_F16)
+        self._load_rows_into(col, n, dim, rows, refine, float(row_err))
+        col.ids, col.documents, col.metadatas = ids, docs, metas
         self.collection = col
+        # appends continue the files only when they hold exactly what this store keeps (same shadow choice); else the next
+        # add rewrites them once in the current format
+        self._persisted_rows = n if (not legacy and bool(meta.get("shadow")) == bool(refine)) else None
         logger.info(f"Loaded existing collection: {self.collection_name} ({col.count()} rows)")
 
-    def persist(self):
-        """Write the slab + sidecars under persist_directory (the PersistentClient analogue): rows in sidecar order
-        whatever the device layout, each file written to a temporary name and moved into place."""
+    def persist(self, first_new_row: Optional[int] = None):
+        """Bring the files under persist_directory up to date.  With first_new_row = the files' row count, only rows
+        [first_new_row, n) are APPENDED (create_index does this: O(batch)); otherwise everything is rewritten."""
         if not self.persist_directory or self.collection is None:
             return
         import torch
         os.makedirs(self.persist_directory, exist_ok=True)
         col = self.collection
-        slab_path, docs_path = self._persist_paths()
-        order = torch.cat([s.rows_global[: s.n].cpu() for s in col.shards]).argsort().numpy()
+        paths = self._persist_paths()
+        n = col.count()
+        append = first_new_row is not None and self._persisted_rows == first_new_row and first_new_row <= n
+        lo = first_new_row if append else 0
+        pdim, dim = col.pdim, col.dim
+        elem = 1 if col.slab_type == nat.SLAB_I8 else 2
 
-        def gather(name):
-            return torch.cat([getattr(s, name)[: s.n].cpu() for s in col.shards]).numpy()[order]
+        def new_rows(name):
+            """rows [lo, n) of a per-shard array, in sidecar order"""
+            parts, order = [], []
+            for sh in col.shards:
+                rg = sh.rows_global[: sh.n]
+                sel = (rg >= lo).nonzero().flatten() if lo else None
+                arr = getattr(sh, name)[: sh.n]
+                parts.append((arr if sel is None else arr[sel]).cpu())
+                order.append((rg if sel is None else rg[sel]).cpu())
+            o = torch.cat(order).argsort()
+            return torch.cat(parts)[o].contiguous().numpy()
 
-        arrays = {"slab": gather("slab"), "n": np.int64(col.n), "dim": np.int64(col.dim), "index_dtype": np.str_(col.index_dtype),
-                  "row_err_max": np.float32(max(sh.row_err_max() for sh in col.shards))}
+        def write(key, arr, row_bytes):
+            mode = "r+b" if (append and os.path.exists(paths[key])) else "wb"
+            with open(paths[key], mode) as fh:
+                if mode == "r+b":
+                    fh.seek(lo * row_bytes)
+                    fh.truncate()                 # drop anything a crashed add left past the header's row count
+                fh.write(arr.tobytes())
+                fh.flush()
+                os.fsync(fh.fileno())
+
+        write("slab", new_rows("slab"), pdim * elem)
         if col.slab_type == nat.SLAB_I8:
-            arrays["scales"] = gather("scales")
+            write("scales", new_rows("scales"), 4)
         if col.refine_fp32:
-            arrays["shadow"] = gather("shadow")
-        tmp = slab_path + ".tmp.npz"
-        np.savez(tmp, **arrays)
-        os.replace(tmp, slab_path)
-        tmp = docs_path + ".tmp"
+            write("shadow", new_rows("shadow"), dim * 4)
+        elif not append and os.path.exists(paths["shadow"]):
+            os.remove(paths["shadow"])
+        # sidecar lines: keep the bytes the header vouches for (the first `lo` rows), replace the rest
+        keep = self._docs_bytes if (append and os.path.exists(paths["docs"])) else 0
+        with open(paths["docs"], "r+b" if keep else "wb") as fh:
+            fh.seek(keep)
+            fh.truncate()
+            for r in range(lo if keep else 0, n):
+                fh.write((json.dumps({"id": col.ids[r], "document": col.documents[r], "metadata": col.metadatas[r]}) + "\n").encode("utf-8"))
+            fh.flush()
+            os.fsync(fh.fileno())
+            self._docs_bytes = fh.tell()
+        meta = {"format": 2, "n": n, "dim": dim, "pdim": pdim, "index_dtype": col.index_dtype, "shadow": bool(col.refine_fp32),
+                "row_err_max": max(sh.row_err_max() for sh in col.shards), "docs_bytes": self._docs_bytes}
+        tmp = paths["meta"] + ".tmp"
         with open(tmp, "w") as fh:
-            json.dump({"ids": col.ids, "documents": col.documents, "metadatas": col.metadatas}, fh)
-        os.replace(tmp, docs_path)
+            json.dump(meta, fh)
+            fh.flush()
+            os.fsync(fh.fileno())
+        os.replace(tmp, paths["meta"])
+        for key in ("legacy_slab", "legacy_docs"):       # superseded
+            if os.path.exists(paths[key]):
+                os.remove(paths[key])
+        self._persisted_rows = n
 
     @staticmethod
     def _chunk_metadata(chunk, fields: Sequence[str]) -> dict:
@@ -373,7 +552,7 @@ class VectorStore:
             col.documents.extend(chunk.text for chunk in chunks)
             col.metadatas.extend(self._chunk_metadata(chunk, fields) for chunk in chunks)
             if self.persist_directory:
-                self.persist()
+                self.persist(first_new_row=start)    # appends rows [start, n) when the files already hold [0, start)
             logger.info(f"Index created successfully! Total documents: {col.count()}")
         except (ValueError, nat.NativeError):
             raise
@@ -388,19 +567,40 @@ class VectorStore:
             return sh.slab_type == nat.SLAB_F16
         return bool(self.refine_exact)
 
-    def _search_shard(self, sh: _Shard, q32, top_k: int, allowed_t, cap: Optional[int] = None):
+    def _filtered_view(self, g: int, sh: _Shard, filt: dict):
+        """The allowed rows shard g owns, compacted ONCE per distinct filter into a sub-slab (+ scales, shadow, row map) and
+        kept with the filter's cache entry: a filtered query then costs one scan of exactly the allowed rows -- no per-query
+        gather, no Python pass over the metadata (the reference hands `where` to ChromaDB, rag/indexing.py:129-130,174)."""
+        import torch
+        ent = filt["shards"].get(g)
+        if ent is None:
+            allowed_t = torch.as_tensor(filt["rows"], dtype=torch.int64, device=sh.device)
+            n = sh.n
+            if sh.identity:
+                local = allowed_t[allowed_t < n]
+            else:
+                local = torch.isin(sh.rows_global[:n], allowed_t).nonzero().flatten()
+            ent = {"n": int(local.numel())}
+            if ent["n"]:
+                ent["slab"] = sh.slab[local].contiguous()
+                ent["scales"] = sh.scales[local].contiguous() if sh.scales is not None else None
+                ent["shadow"] = sh.shadow[local].contiguous() if sh.shadow is not None else None
+                ent["row_map"] = sh.rows_global[local].contiguous()
+            filt["shards"][g] = ent
+        return ent
+
+    def _search_shard(self, sh: _Shard, q32, top_k: int, filt, cap: Optional[int] = None, g: int = 0):
         """q32: fp32 [nq, dim] on the shard's device -> (scores [nq, top_k], GLOBAL sidecar rows [nq, top_k], certificate
         status int32 [nq] or None) there.  Nothing here waits for the device."""
         import torch
         nq = q32.shape[0]
         slab, scales, shadow, n = sh.slab, sh.scales, sh.shadow, sh.n
         row_map = None if sh.identity else (sh.rows_global[:n] if n else None)
-        if allowed_t is not None and n:   # metadata filter: scan a gathered sub-slab of the allowed rows this shard owns
-            local = torch.isin(sh.rows_global[:n], allowed_t.to(sh.device)).nonzero().flatten()
-            slab = sh.slab[local].contiguous()
-            scales = sh.scales[local].contiguous() if scales is not None else None
-            shadow = sh.shadow[local].contiguous() if shadow is not None else None
-            row_map, n = sh.rows_global[local], int(local.numel())
+        if filt is not None and n:        # metadata filter: scan the cached, compacted sub-slab of the allowed rows this shard owns
+            ent = self._filtered_view(g, sh, filt)
+            n = ent["n"]
+            if n:
+                slab, scales, shadow, row_map = ent["slab"], ent["scales"], ent["shadow"], ent["row_map"]
         if n == 0:
             return (torch.full((nq, top_k), float("-inf"), dtype=torch.float32, device=sh.device),
                     torch.full((nq, top_k), -1, dtype=torch.int64, device=sh.device), None)
@@ -427,31 +627,34 @@ class VectorStore:
         return s, i, status
 
     def _topk_large(self, sh: _Shard, q32, slab, scales, shadow, n: int, top_k: int):
-        """top_k above the scan kernels' limit (the reference accepts any n_results, rag/indexing.py:152-153):
-        all scores of a row block through the library's GEMM kernel (crs_gemm_f16, fp32 out), device top-k per
-        block, final order by two stable sorts (score desc, row asc).  int8 rows are widened per block."""
+        """top_k above the scan kernels' limit (the reference accepts any n_results, rag/indexing.py:152-153): all slab scores
+        of a row block through the library's GEMM kernel (crs_gemm_f16, fp32 out), device top-k per block, order by two
+        stable sorts (score desc, row asc).  int8 rows are widened per block.  With the fp32 shadow the slab pass over-fetches
+        by half and the candidates are re-scored in fp32 by the library (crs::score_rows_f32) before the final order -- the
+        over-fetch re-rank without a certificate (that exists for top_k <= 64)."""
         import torch
         from rag._encoder import gemm_f16
         q16 = nat.queries_to_f16(q32, nat.SLAB_F16)
         if q16.shape[1] != slab.shape[1]:            # int8 slabs pad rows to 256 elements
             q16 = torch.nn.functional.pad(q16, (0, slab.shape[1] - q16.shape[1]))
         nq = q32.shape[0]
+        keep = min(n, top_k + max(64, top_k // 2)) if shadow is not None else top_k
         best_s = torch.empty((nq, 0), dtype=torch.float32, device=sh.device)
         best_i = torch.empty((nq, 0), dtype=torch.int64, device=sh.device)
         block = 1 << 16
         zero = torch.zeros((nq, min(block, n)), dtype=torch.float32, device=sh.device)
         for lo in range(0, n, block):
             hi = min(n, lo + block)
-            if shadow is not None:                   # exact fp32 scores when the store keeps the fp32 rows
-                sc = torch.nn.functional.normalize(q32, p=2, dim=1, eps=1e-12) @ shadow[lo:hi].T
-            else:
-                w = slab[lo:hi] if scales is None else (slab[lo:hi].float() * scales[lo:hi, None]).half()
-                sc = gemm_f16(q16, w.contiguous(), residual=zero[:, : hi - lo].contiguous(), mode=2)
-            ts, ti = sc.topk(min(top_k, hi - lo), dim=1)
+            w = slab[lo:hi] if scales is None else (slab[lo:hi].float() * scales[lo:hi, None]).half()
+            sc = gemm_f16(q16, w.contiguous(), residual=zero[:, : hi - lo].contiguous(), mode=2)
+            ts, ti = sc.topk(min(keep, hi - lo), dim=1)
             best_s, best_i = torch.cat([best_s, ts], 1), torch.cat([best_i, ti + lo], 1)
-            if best_s.shape[1] > 4 * top_k:
-                best_s, best_i = self._order(best_s, best_i, top_k)
-        s, i = self._order(best_s, best_i, top_k)
+            if best_s.shape[1] > 4 * keep:
+                best_s, best_i = self._order(best_s, best_i, keep)
+        s, i = self._order(best_s, best_i, keep)
+        if shadow is not None:
+            qn = torch.nn.functional.normalize(q32, p=2, dim=1, eps=1e-12).contiguous()
+            s, i = self._order(nat.score_rows_f32(qn, shadow, n, 0, i), i, top_k)
         if s.shape[1] < top_k:
             pad = top_k - s.shape[1]
             s = torch.nn.functional.pad(s, (0, pad), value=float("-inf"))
@@ -468,19 +671,17 @@ class VectorStore:
         o = torch.argsort(torch.where(i >= 0, s, float("-inf")), dim=1, descending=True, stable=True)[:, :k]
         return torch.gather(s, 1, o), torch.gather(i, 1, o)
 
-    def _topk_device(self, q32, top_k: int, allowed_rows=None):
-        """q32: fp32 [nq, dim] on the first device -> (scores [nq, k] fp32, sidecar rows [nq, k] int64) there."""
+    def _topk_device(self, q32, top_k: int, filt=None):
+        """q32: fp32 [nq, dim] on the first device -> (scores [nq, k] fp32, sidecar rows [nq, k] int64) there.
+        filt: a filter cache entry (_filter_entry) or None."""
         import torch
         col = self.collection
         nq = q32.shape[0]
-        allowed_t = None
-        if allowed_rows is not None:
-            allowed_t = torch.as_tensor(allowed_rows, dtype=torch.int64, device=col.device)
         parts = []
-        for sh in col.shards:          # launches are asynchronous: the devices scan their shards concurrently
+        for g, sh in enumerate(col.shards):   # launches are asynchronous: the devices scan their shards concurrently
             with torch.cuda.device(sh.device):
                 q = q32 if q32.device == sh.device else q32.to(sh.device, non_blocking=True)
-                parts.append(self._search_shard(sh, q, top_k, allowed_t))
+                parts.append(self._search_shard(sh, q, top_k, filt, g=g))
         # certificate bookkeeping (the one host wait of a refined search; search_batch reads the results right after anyway):
         # status 2 = an escalated query's band held more rows than the list -- repeat that shard with a longer list
         tally = {"queries": nq, "certified": 0, "escalated": 0, "unproven": 0}
@@ -494,7 +695,7 @@ class VectorStore:
                 cap = min(nat.EXACT_MAX_CAP, cap * 4)
                 with torch.cuda.device(sh.device):
                     q = q32 if q32.device == sh.device else q32.to(sh.device)
-                    parts[g] = self._search_shard(sh, q, top_k, allowed_t, cap=cap)
+                    parts[g] = self._search_shard(sh, q, top_k, filt, cap=cap, g=g)
                 st = parts[g][2].cpu().numpy()
             if (st == 2).any():
                 logger.warning(f"{int((st == 2).sum())} queries have more than {nat.EXACT_MAX_CAP} rows within the error band of "
@@ -528,29 +729,25 @@ class VectorStore:
             s, i = _shard.allgather_merge(dist, wb.buf, wb.gathered, nq, top_k, top_k, nat.merge_topk_wire)
         return s, i
 
-    def _filter_rows(self, where: Optional[dict], where_document: Optional[dict]):
+    def _filter_entry(self, where: Optional[dict], where_document: Optional[dict]):
+        """Cache entry of a distinct (where, where_document) pair: the allowed sidecar rows (SlabCollection.rows_matching:
+        an inverted metadata index, no per-query pass over the rows) and, filled by the first search, each shard's compacted
+        sub-slab.  None = no filter.  Entries die when rows are added; the eight most recent filters are kept."""
         if not where and not where_document:
             return None
         col = self.collection
-        keep = []
-        for row, (meta, doc) in enumerate(zip(col.metadatas, col.documents)):
-            ok = True
-            for key, want in (where or {}).items():
-                if isinstance(want, dict):  # {"$eq": v} / {"$ne": v} / {"$in": [...]}
-                    (op, val), = want.items()
-                    have = meta.get(key)
-                    ok &= {"$eq": have == val, "$ne": have != val,
-                           "$in": have in val if isinstance(val, (list, tuple)) else False}.get(op, False)
-                else:
-                    ok &= meta.get(key) == want
-            for op, val in (where_document or {}).items():
-                if op == "$contains":
-                    ok &= val in doc
-                elif op == "$not_contains":
-                    ok &= val not in doc
-            if ok:
-                keep.append(row)
-        return keep
+        try:
+            key = json.dumps([where, where_document], sort_keys=True, default=repr)
+        except TypeError:
+            key = repr((where, where_document))
+        ent = self._filters.get(key)
+        if ent is None or ent["n"] != col.count():
+            ent = {"n": col.count(), "rows": col.rows_matching(where, where_document), "shards": {}}
+            self._filters.pop(key, None)
+            while len(self._filters) >= 8:
+                self._filters.pop(next(iter(self._filters)))
+            self._filters[key] = ent
+        return ent
 
     def search(self, query_embedding, top_k: int = 5, where: Optional[dict] = None,
                where_document: Optional[dict] = None) -> Dict[str, Any]:
@@ -635,10 +832,10 @@ class VectorStore:
             q32 = torch.from_numpy(np.ascontiguousarray(query_embeddings, dtype=np.float32)).to(col.device)
         if q32.shape[1] != col.dim:
             raise ValueError(f"Query dimension {q32.shape[1]} doesn't match the index dimension {col.dim}")
-        allowed = self._filter_rows(where, where_document)
-        if allowed is not None and len(allowed) == 0:
+        filt = self._filter_entry(where, where_document)
+        if filt is not None and len(filt["rows"]) == 0:
             return {k: [[] for _ in range(nq)] for k in _EMPTY}
-        scores, rows = self._topk_device(q32, top_k, allowed)
+        scores, rows = self._topk_device(q32, top_k, filt)
         sh, rh = scores.cpu().numpy(), rows.cpu().numpy()
         dist = (np.float32(1.0) - sh).astype(np.float64)          # one vectorised pass; float(np.float32) per hit was the cost
         ids_l, docs_l, metas_l = col.ids, col.documents, col.metadatas
@@ -657,8 +854,10 @@ class VectorStore:
         if self.collection:
             self.collection = None
             self._wire = {}
+            self._filters = {}
+            self._persisted_rows = None
             if self.persist_directory:
-                for path in self._persist_paths():
+                for path in self._persist_paths().values():
                     if os.path.exists(path):
                         os.remove(path)
             logger.info(f"Deleted collection: {self.collection_name}")

@@ -86,6 +86,12 @@ int crs_merge_topk(const float* scores_dev, const int64_t* ids_dev, int nlists, 
 int crs_rescore_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows,
                     int64_t id_base, int k, float* scores_dev, int64_t* ids_dev, void* stream);
 
+/* The scoring half alone, for candidate lists of ANY length k (VectorStore.search with top_k > CRS_MAX_K orders them with a
+ * device sort): scores[i, j] = <q32[i, :], shadow[ids[i, j] - id_base, :]>; entries with ids < 0 get -inf, entries of other
+ * shards are left as they are. */
+int crs_score_rows_f32(const float* q32_dev, int nq, int dim, const float* shadow_dev, int64_t n_rows, int64_t id_base, int k,
+                       const int64_t* ids_dev, float* scores_dev, void* stream);
+
 /* Over-fetch + exact re-rank in one launch (Recall@10 = 1.0 against the fp32 ranking the
  * reference's ChromaDB collection keeps, rag/indexing.py:114-119).  cand_ids [nq, k_in] are the rows a
  * crs_cosine_topk call with k = k_in >= k_out found in the fp16 / int8 slab; each is re-scored as the fp32

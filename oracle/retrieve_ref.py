@@ -113,6 +113,54 @@ def retrieve(query: str, *, search: Callable[..., Dict], embed: Callable[[List[s
 # ------------------------------------------------------------------------------------------------
 # VectorStore contract (rag/indexing.py:57-211) over a numpy matrix: the CPU statement of what
 # create_index / search / get_stats must return, used to check the HIP-backed store's host logic.
+def _where_ok(meta: dict, where: dict) -> bool:
+    """One row against a ChromaDB `where` document, evaluated the slow, obvious way (chromadb==1.3.0 is not vendored; these are
+    its documented operators: plain equality, $eq $ne $in $nin $gt $gte $lt $lte, $and / $or)."""
+    for key, want in where.items():
+        if key == "$and":
+            ok = all(_where_ok(meta, w) for w in want)
+        elif key == "$or":
+            ok = any(_where_ok(meta, w) for w in want)
+        else:
+            have = meta.get(key)
+            op, val = ("$eq", want)
+            if isinstance(want, dict):
+                (op, val), = want.items()
+            num = lambda x: isinstance(x, (int, float)) and not isinstance(x, bool)           # noqa: E731
+            if op == "$eq":
+                ok = have == val
+            elif op == "$ne":
+                ok = have != val
+            elif op == "$in":
+                ok = isinstance(val, (list, tuple)) and have in val
+            elif op == "$nin":
+                ok = isinstance(val, (list, tuple)) and have not in val
+            elif op in ("$gt", "$gte", "$lt", "$lte"):
+                ok = num(have) and num(val) and {"$gt": have > val, "$gte": have >= val, "$lt": have < val, "$lte": have <= val}[op] if num(have) and num(val) else False
+            else:
+                ok = False
+        if not ok:
+            return False
+    return True
+
+
+def _doc_ok(text: str, cond: dict) -> bool:
+    for op, val in cond.items():
+        if op == "$contains":
+            ok = val in text
+        elif op == "$not_contains":
+            ok = val not in text
+        elif op == "$and":
+            ok = all(_doc_ok(text, c) for c in val)
+        elif op == "$or":
+            ok = any(_doc_ok(text, c) for c in val)
+        else:
+            ok = True
+        if not ok:
+            return False
+    return True
+
+
 class StoreRef:
     def __init__(self):
         self.ids: List[str] = []
@@ -155,14 +203,10 @@ class StoreRef:
         q = q / max(float(np.linalg.norm(q)), 1e-12)
         cos = self.vecs.astype(np.float64) @ q.astype(np.float64)
         mask = np.ones(self.count(), dtype=bool)
-        if where:
-            for key, val in where.items():
-                mask &= np.array([m.get(key) == val for m in self.metas])
-        for op, val in (where_document or {}).items():       # chromadb document filters the reference forwards (:174)
-            if op == "$contains":
-                mask &= np.array([val in t for t in self.docs])
-            elif op == "$not_contains":
-                mask &= np.array([val not in t for t in self.docs])
+        if where:                                            # chromadb metadata filters the reference forwards (:129-130,174)
+            mask &= np.array([_where_ok(m, where) for m in self.metas])
+        if where_document:                                   # ... and its document filters
+            mask &= np.array([_doc_ok(t, where_document) for t in self.docs])
         idx = np.nonzero(mask)[0]
         order = idx[np.lexsort((idx, -cos[idx]))][:top_k]
         return {

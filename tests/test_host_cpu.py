@@ -391,3 +391,38 @@ def test_ascii_fast_path_of_basic_tokenize_equals_the_general_path():
             tail = tk.basic_tokenize("x \u00e9", lower)[-1]
             gen = tk.basic_tokenize(text + " " + "\u00e9", lower)
             assert gen[-1] == tail and gen[:-1] == fast, (repr(text), fast, gen)
+
+
+def test_metadata_filters_inverted_index_equals_row_by_row_evaluation():
+    """SlabCollection.rows_matching (inverted index; product) against oracle/retrieve_ref._where_ok / _doc_ok (one row at
+    a time) on random metadata, every operator the reference may forward to ChromaDB (rag/indexing.py:129-130,174)."""
+    from oracle import retrieve_ref as rr
+    from rag.indexing import SlabCollection
+    rng = np.random.default_rng(3)
+    col = SlabCollection("f", "fp16", False, [])
+    words = ["alpha", "beta", "gamma", "delta"]
+    for r in range(700):
+        meta = {"page_number": int(rng.integers(1, 6)), "tokens": int(rng.integers(3, 40))}
+        if rng.random() < 0.5:
+            meta["section"] = str(rng.choice(["intro", "method", "results"]))
+        if rng.random() < 0.2:
+            meta["score"] = float(rng.integers(0, 4)) / 2
+        col.ids.append(f"chunk_{r}"); col.metadatas.append(meta)
+        col.documents.append(" ".join(rng.choice(words, size=5)))
+        if r == 300:          # the index is extended as rows arrive
+            assert list(col.rows_matching({"page_number": 2}, None)) == [i for i, m in enumerate(col.metadatas) if m["page_number"] == 2]
+    cases = [({"page_number": 2}, None), ({"page_number": {"$eq": 2}}, None), ({"page_number": {"$ne": 2}}, None),
+             ({"section": "intro"}, None), ({"section": {"$ne": "intro"}}, None), ({"section": None}, None),
+             ({"page_number": {"$in": [1, 3, 77]}}, None), ({"page_number": {"$nin": [1, 3]}}, None), ({"page_number": {"$in": []}}, None),
+             ({"tokens": {"$gt": 20}}, None), ({"tokens": {"$lte": 5}}, None), ({"score": {"$gte": 1}}, None), ({"score": {"$lt": 0.75}}, None),
+             ({"page_number": 2, "section": "method"}, None), ({"$and": [{"page_number": {"$gte": 2}}, {"tokens": {"$lt": 30}}]}, None),
+             ({"$or": [{"section": "results"}, {"page_number": 5}]}, None), ({"page_number": {"$regex": "x"}}, None),
+             ({"nokey": 1}, None), ({"page_number": 2.0}, None), ({"page_number": "2"}, None),
+             (None, {"$contains": "beta"}), (None, {"$not_contains": "beta"}), ({"page_number": 3}, {"$contains": "gamma alpha"}),
+             (None, {"$or": [{"$contains": "alpha alpha"}, {"$contains": "delta delta"}]}),
+             (None, {"$and": [{"$contains": "alpha"}, {"$not_contains": "beta"}]})]
+    for where, wdoc in cases:
+        want = [i for i in range(700) if (not where or rr._where_ok(col.metadatas[i], where)) and (not wdoc or rr._doc_ok(col.documents[i], wdoc))]
+        got = col.rows_matching(where, wdoc)
+        assert got.tolist() == want, (where, wdoc)
+    assert col.rows_matching(None, None) is None and col.rows_matching({}, {}) is None

@@ -161,8 +161,11 @@ def test_w2_dump_is_bounded_and_the_fallback_is_exact(cuda):
     with the shard.  Past 256 entries per (query, stream) the planner must hand over to the bounded chain kernels
     (10 M x 768 at 256 queries would be 640 MB of workspace, 312 k merge candidates per query), and both sides of
     that switch -- and the two-level merge that serves dumps of > 8192 candidates -- return the oracle's answer."""
+    import os
     import torch
     from rag import _native as nat
+    if os.environ.get("CRS_SCAN_TB") == "0":
+        pytest.skip("this run forces the threshold kernels (tests/test_scan_classic_gpu.py)")
     assert "scan_w2" in nat.scan_plan_describe(256, 768, 10, 1_000_000)                 # C3: the dump form
     assert "scan_w2" in nat.scan_plan_describe(256, 768, 10, 2_000_000)                 # 62500 tiles / 256 streams = 245
     plan_big = nat.scan_plan_describe(256, 768, 10, 10_000_000)

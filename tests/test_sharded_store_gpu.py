@@ -101,7 +101,7 @@ def test_two_shard_persistence_round_trip_and_corrupt_file(cuda, tmp_path):
     assert b.get_stats()["count"] == n and [b.search(q[i], top_k=5) for i in range(4)] == want
     c = VectorStore({"persist_directory": str(tmp_path), "collection_name": "p"})    # ... or onto one device
     assert [c.search(q[i], top_k=5)["ids"] for i in range(4)] == [w["ids"] for w in want]
-    with open(tmp_path / "p.slab.npz", "r+b") as fh:              # truncate: must raise, not silently start empty
+    with open(tmp_path / "p.slab.bin", "r+b") as fh:              # truncate: must raise, not silently start empty
         fh.truncate(1000)
     with pytest.raises(RuntimeError, match="unreadable"):
         VectorStore(dict(cfg))

@@ -113,6 +113,75 @@ def test_persistence_round_trip(cuda, tmp_path):
     assert VectorStore(cfg).collection is None
 
 
+def test_persistence_appends_and_survives_a_torn_add(cuda, tmp_path):
+    """create_index appends to the row files (O(batch), not a rewrite of the index); whatever a crashed add left past the
+    header's row count is ignored on load and overwritten by the next add; the round-2 .npz format is still read."""
+    import json
+    import os
+    from rag.indexing import VectorStore
+    cfg = {"collection_name": "inc", "persist_directory": str(tmp_path), "index_dtype": "int8"}
+    chunks, emb = _chunks(90, 4), scan_ref.synth_corpus(90, 384, seed=4)
+    a = VectorStore(cfg)
+    a.create_index(chunks[:40], emb[:40])
+    size40 = os.path.getsize(tmp_path / "inc.slab.bin")
+    ino = os.stat(tmp_path / "inc.slab.bin").st_ino
+    a.create_index(chunks[40:70], emb[40:70])
+    assert os.path.getsize(tmp_path / "inc.slab.bin") == size40 // 40 * 70          # grew by exactly the batch ...
+    assert os.stat(tmp_path / "inc.slab.bin").st_ino == ino                          # ... in place (not re-created)
+    assert json.load(open(tmp_path / "inc.meta.json"))["n"] == 70
+    # a torn add: rows and sidecar lines past the header (the header is written last)
+    for name, junk in (("inc.slab.bin", b"\x7f" * 5000), ("inc.scales.bin", b"\x00" * 40), ("inc.shadow.bin", b"\x01" * 3000),
+                       ("inc.docs.jsonl", b'{"id": "ghost", "document": "x", "meta')):
+        with open(tmp_path / name, "ab") as fh:
+            fh.write(junk)
+    b = VectorStore(cfg)
+    assert b.get_stats()["count"] == 70 and "ghost" not in b.collection.ids
+    q = scan_ref.synth_queries(emb, 2, seed=2)
+    want = [a.search(q[i], top_k=5) for i in range(2)]
+    assert [b.search(q[i], top_k=5) for i in range(2)] == want
+    b.create_index(chunks[70:], emb[70:])                                            # overwrites the junk
+    a.create_index(chunks[70:], emb[70:])
+    c = VectorStore(cfg)
+    assert c.get_stats()["count"] == 90 and [c.search(q[i], top_k=5) for i in range(2)] == [a.search(q[i], top_k=5) for i in range(2)]
+    assert os.path.getsize(tmp_path / "inc.slab.bin") == size40 // 40 * 90
+    # the round-2 format (one .npz + one .json, rewritten per add) still opens, and the next add converts it
+    col = c.collection
+    legacy = tmp_path / "old"
+    os.makedirs(legacy)
+    np.savez(legacy / "inc.slab.npz", slab=col.slab[:90].cpu().numpy(), scales=col.scales[:90].cpu().numpy(),
+             shadow=col.shadow[:90].cpu().numpy(), n=np.int64(90), dim=np.int64(384), index_dtype=np.str_("int8"))
+    json.dump({"ids": col.ids, "documents": col.documents, "metadatas": col.metadatas}, open(legacy / "inc.docs.json", "w"))
+    d = VectorStore(dict(cfg, persist_directory=str(legacy)))
+    assert d.get_stats()["count"] == 90 and [d.search(q[i], top_k=5)["ids"] for i in range(2)] == [w["ids"] for w in [a.search(q[i], top_k=5) for i in range(2)]]
+    d.create_index(_chunks(95, 4)[90:], scan_ref.synth_corpus(5, 384, seed=77))
+    assert os.path.exists(legacy / "inc.meta.json") and not os.path.exists(legacy / "inc.slab.npz")
+    assert VectorStore(dict(cfg, persist_directory=str(legacy))).get_stats()["count"] == 95
+
+
+def test_filters_use_the_inverted_index_and_cached_subslabs(cuda):
+    from rag.indexing import VectorStore
+    n = 4000
+    chunks = _chunks(n, 7)
+    emb = scan_ref.synth_corpus(n, 384, seed=7)
+    store, ref = VectorStore({}), rr.StoreRef()
+    store.create_index(chunks, emb); ref.create_index(chunks, emb)
+    q = scan_ref.synth_queries(emb, 6, seed=8)
+    for where, wdoc in (({"page_number": 2}, None), ({"page_number": {"$in": [1, 3]}}, None), ({"page_number": {"$ne": 0}}, None),
+                        (None, {"$contains": "beta"}), ({"page_number": 1}, {"$not_contains": "beta"}), ({"page_number": {"$gt": 1}}, None)):
+        for i in range(3):
+            assert store.search(q[i], top_k=7, where=where, where_document=wdoc)["ids"] == \
+                ref.search(q[i], top_k=7, where=where, where_document=wdoc)["ids"], (where, wdoc)
+    assert len(store._filters) == 6 and all(("shards" in e) for e in store._filters.values())
+    ent = store._filter_entry({"page_number": 2}, None)
+    sub = ent["shards"][0]
+    assert sub["n"] == len(ent["rows"]) and sub["slab"].shape[0] == sub["n"]         # compacted once, kept
+    assert store._filter_entry({"page_number": 2}, None) is ent                       # ... and reused
+    batch = store.search_batch(q, top_k=5, where={"page_number": 2})
+    assert [batch["ids"][i] for i in range(6)] == [ref.search(q[i], top_k=5, where={"page_number": 2})["ids"][0] for i in range(6)]
+    store.create_index(_chunks(n + 10, 7)[n:], scan_ref.synth_corpus(10, 384, seed=9))   # new rows: cached entries are stale
+    assert store._filter_entry({"page_number": 2}, None) is not ent
+
+
 def test_pipeline_end_to_end_vs_oracle(cuda):
     """index_documents -> retrieve through the product classes (synthetic MiniLM weights, hash
     tokeniser) vs oracle encoder + StoreRef + retrieve_ref fed the same token ids."""
