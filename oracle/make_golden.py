@@ -262,6 +262,23 @@ def gen_clean_text():
         json.dump({"clean": cases, "files": files, "sections": sections}, fh, ensure_ascii=True)
 
 
+def gen_c1_known_answers():
+    """tests/golden/c1_known_answers.json: the reference's only end-to-end known answers for the hot path -- per question
+    the `context_scores` of the retrieved chunks (+ chunk count and context length) as its committed Kaggle run logged them
+    (/root/reference/results/mistral_fp16/detailed_responses.json; identical in the AWQ run, i.e. they depend on the
+    embed -> index -> retrieve path alone).  Data only: questions and numbers."""
+    src = "/root/reference/results/mistral_fp16/detailed_responses.json"
+    with open(src) as fh:
+        rows = json.load(fh)
+    out = {"_source": "results/mistral_fp16/detailed_responses.json of the reference (config.json: all-MiniLM-L6-v2, top_k 3, rerank, "
+                      "diversity_penalty 0.1, similarity_threshold 0.3; data/2308.07633v4-clean.pdf)",
+           "cases": [{"question": r["question"], "context_scores": r["context_scores"], "num_chunks_retrieved": r["num_chunks_retrieved"],
+                      "context_length_chars": r["context_length_chars"]} for r in rows]}
+    with open(os.path.join(OUT, "c1_known_answers.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("c1_known_answers.json:", len(out["cases"]), "questions")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     gen_clean_text()
@@ -276,6 +293,7 @@ def main():
     gen_encoder("bge", er.BGE_BASE, batch=2, seq=16, seed=13)
     gen_scan()
     gen_ir_metrics()
+    gen_c1_known_answers()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
