@@ -295,6 +295,8 @@ def main():
                          "encodes Qb / N queries and the embeddings are all-gathered first (two collectives; the encoder's kernels "
                          "then cover 1/N of the CUs, so the chains of the in-flight batches run side by side).  auto = sharded "
                          "from 4 GPUs on (when N divides the batch), replicated below")
+    ap.add_argument("--enc-small-lds", default="auto", choices=("auto", "on", "off"),
+                    help="the encoder's <= 48 KB-of-LDS kernel forms (auto: with role lanes only)")
     ap.add_argument("--k-scan", type=int, default=0, help="candidates the scan over-fetches for the fp32 re-rank (0: 32)")
     ap.add_argument("--exact", default="auto", choices=("auto", "on", "off"),
                     help="in-stream escalation of queries whose list the certificate could not prove (auto: fp16 slabs on, int8 empirical)")
@@ -428,7 +430,8 @@ def main():
                                enc_lanes=args.enc_lanes, search_lanes=args.search_lanes, graphs=not args.no_graph,
                                dist=dist if multi else None, world=world, rank=rank, queries_per_rank=not strong,
                                encode_shard=(world if (strong and multi and want_shard) else 1),
-                               proxy_encode_shard=args.proxy_encode_shard, encode=not args.scan_only)
+                               proxy_encode_shard=args.proxy_encode_shard, encode=not args.scan_only,
+                               enc_small_lds={"auto": "auto", "on": True, "off": False}[args.enc_small_lds])
 
     exact_mode = {"auto": "auto", "on": True, "off": False}[args.exact]
     eng = make_engine(refine, exact_mode)

@@ -51,7 +51,8 @@ class RetrievalEngine:
     def __init__(self, encoder, view: ShardView, queries_per_batch: int, seq: int, top_k: int, *, k_scan: int = 32,
                  refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 8, lanes: str = "auto",
                  enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
-                 queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True):
+                 queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True,
+                 enc_small_lds="auto"):
         """queries_per_batch: the GLOBAL batch every rank searches (strong scaling), or with ``queries_per_rank`` the queries
         THIS rank contributes (weak scaling: the scan then sees world x that many).  encode_shard = W > 1: each rank encodes
         Qb / W queries and the embeddings are all-gathered first (two collectives per batch instead of one).
@@ -86,6 +87,9 @@ class RetrievalEngine:
         scan_bytes = view.n * self.pd * (1 if view.slab_type == nat.SLAB_I8 else 2)
         hidden = encoder.shape.hidden if encoder is not None else view.dim
         self.pipelined = lanes == "split" or (lanes == "auto" and self.encode and hidden <= 384 and scan_bytes >= (512 << 20))
+        # <= 48 KB kernel forms of the encoder (they can start beside a scan's resident workgroups): with role lanes always;
+        # 'auto' otherwise keeps the default forms
+        self.small_lds = self.pipelined if enc_small_lds == "auto" else bool(enc_small_lds)
         self.n_ctx = max(1, int(n_ctx))
         self.use_graph = bool(graphs)
         if self.pipelined:
@@ -153,7 +157,7 @@ class RetrievalEngine:
     def _seg_encode(self, c: _Ctx) -> None:      # token ids -> fp32 embeddings + the scan's fp16 query block
         if self.encode:
             self.enc.forward(c.ids, c.lens, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=self.view.slab_type,
-                             small_lds=self.pipelined)
+                             small_lds=self.small_lds)
         else:
             nat.queries_to_f16(c.q_out, self.view.slab_type, out=c.q16)
 

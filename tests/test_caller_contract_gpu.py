@@ -79,7 +79,8 @@ def test_main_py_call_sequence(cuda, tmp_path):
         assert {"text", "score", "distance", "metadata", "chunk_id"} <= set(chunk)
     assert isinstance(result["answer"], str) and result["answer"].startswith("stub answer")
     assert isinstance(pipeline.query("what is attention"), str)   # no flags -> the bare answer string
-    assert os.path.exists(tmp_path / "vector_db" / "rag_documents.slab.npz")        # persist_directory honoured
+    assert os.path.exists(tmp_path / "vector_db" / "rag_documents.meta.json")       # persist_directory honoured
+    assert os.path.exists(tmp_path / "vector_db" / "rag_documents.slab.bin")
     # a second pipeline on the same persist directory re-opens the collection (PersistentClient behaviour)
     again = RAGPipeline(_rag_config(tmp_path)); again.setup(mi)
     assert again.get_stats()["vector_store"]["count"] == stats["vector_store"]["count"]

@@ -121,9 +121,10 @@ def test_c2_full_size(cuda):
 
 @pytest.mark.parametrize("n,d,nq,k,kind", [(300_000, 384, 64, 20, "f16"), (300_000, 384, 7, 32, "f16"), (300_000, 768, 64, 32, "i8"),
                                             (300_000, 128, 64, 17, "f16"), (300_000, 384, 33, 40, "f16"), (300_000, 256, 64, 64, "f16"),
-                                            (160_000, 768, 64, 40, "f16"), (300_000, 768, 64, 40, "i8")])
+                                            (160_000, 768, 64, 40, "f16"), (300_000, 768, 64, 40, "i8"), (300_000, 384, 64, 56, "f16"),
+                                            (200_000, 512, 64, 48, "f16")])
 def test_long_chain_matches_oracle_and_threshold_kernels(cuda, n, d, nq, k, kind):
-    """16 < k <= 64 on streams too long for the dump form: scan_tb / scan_i8 with a 32- / 48- / 64-slot chain.  Checked against the
+    """16 < k <= 64 on streams too long for the dump form: scan_tb / scan_i8 with a 32- / 40- / 48- / 56- / 64-slot chain.  Checked against the
     oracle; test_scan_classic_gpu.py re-runs this module on the threshold kernels (CRS_SCAN_TB=0)."""
     import torch
     from oracle import scan_ref
@@ -138,7 +139,14 @@ def test_long_chain_matches_oracle_and_threshold_kernels(cuda, n, d, nq, k, kind
     q16 = nat.queries_to_f16(torch.from_numpy(q).to(cuda), st)
     import os
     if os.environ.get("CRS_SCAN_TB", "1") != "0" and os.environ.get("CRS_SCAN_LONG_CHAIN", "1") != "0":
-        want = ",32>" if k <= 32 else (",64>" if (d <= 384 and kind == "f16") else ",48>")
+        # chain lengths whose registers fit without scratch (tools/check_resources.py): 64 slots for 256-element fp16 rows, 48 / 56
+        # for 384, 48 for 512 / 640, 40 for 768; int8: 48 up to 768
+        if k <= 32:
+            want = ",32>"
+        elif kind == "i8":
+            want = ",48>"
+        else:
+            want = {256: ",64>", 384: ",48>" if k <= 48 else ",56>", 512: ",48>", 640: ",48>", 768: ",40>"}[pd]
         assert want in nat.scan_plan_describe(nq, d, k, n, slab_type=st)                # the long-chain plan
     s, i = nat.cosine_topk(q16, slab, n, d, k, slab_type=st, scales=scales)
     torch.cuda.synchronize()
