@@ -236,15 +236,19 @@ def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out
     return out_scores, out_ids
 
 
-def overfetch(nq: int, top_k: int, want: int = 32) -> int:
-    """Candidates the scan fetches for the fp32 re-rank: `want` (32: the certificate then holds for all but ~1e-5 of random
-    queries), except that launches of more than 64 queries keep to 16 when top_k allows -- the large-batch kernels
-    (scan_wide.hip) carry a 16-slot chain, and 32 candidates would send those launches to the 64-query kernel once per
-    query block.  Never below top_k, never above MAX_K."""
-    k = max(int(top_k), int(want))
-    if nq > 64 and top_k <= 16:
-        k = max(int(top_k), min(int(want), 16))
-    return min(MAX_K, k)
+def overfetch(nq: int, top_k: int, want: int = 32, n_rows: int = 1 << 62) -> int:
+    """Candidates the scan fetches for the fp32 re-rank (never below top_k, never above MAX_K).
+    `want` (32) on shards of >= 4 M rows, where the top scores crowd together (10 M x 384: about 1e-3 apart at rank 10) and the
+    certificate holds for all but ~1e-5 of random queries with 32 candidates but only all but ~3e-4 with 16 -- an escalation
+    there costs a second sweep of the whole shard.  16 on smaller shards: the same gaps are wider (fewer rows in the tail), an
+    escalation sweep is short, and the longer chain / tile refine / merge of 32 candidates measured 16 % of a 1.25 M-row
+    shard's batch (0.301 -> 0.259 ms: one rank of an 8-GPU step).  Launches of more than 64 queries keep to 16 when top_k
+    allows: the large-batch kernels (scan_wide.hip) carry a 16-slot chain, and 32 candidates would send those launches to the
+    64-query kernel once per query block."""
+    want = int(want)
+    if n_rows < 4_000_000 or (nq > 64 and top_k <= 16):
+        want = min(want, 16)
+    return min(MAX_K, max(int(top_k), want))
 
 
 def exact_workspace_bytes(nq: int, cap: int = EXACT_CAP) -> int:
