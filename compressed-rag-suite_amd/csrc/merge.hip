@@ -132,11 +132,11 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   if (tid == 0) sh_cnt = 0;
   for (int r = tid; r < k_out; r += kThreads) { os[r] = kNegInf; oi[r] = -1; }
 
-  // Fast path (a query's lists contiguous, m <= 8192: every stage-2 merge of the scan): each thread
-  // pulls its <= 32 strided candidates into registers with all loads in flight at once, so the
+  // Fast path (a query's lists contiguous, m <= 16384: every stage-2 merge of the scan): each thread
+  // pulls its <= 64 strided candidates into registers with all loads in flight at once, so the
   // candidate set crosses the memory system exactly once (the generic path below walks it twice in
   // batches of 8 and was bound by those serial round trips).
-  constexpr int kRegE = 32;
+  constexpr int kRegE = 64;
   const bool cached = contig && n_pass <= kRegE;
   float cs[kRegE];
   IdT ci[kRegE];
@@ -239,10 +239,12 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
 }  // namespace
 
 // stage-2 layout: [nq, nlists, k_in] (a query's candidates are contiguous)
-// Slices of a two-level stage-2 merge: whole lists, at most 8192 candidates (the register-cached path) per workgroup.
+// Slices of a two-level stage-2 merge: whole lists, at most 16384 candidates (the register-cached path: 64 per thread) per
+// workgroup -- 512 streams x 32 chain slots (C4 at k' = 32) still merge in ONE launch.
+constexpr int kSliceCand = 16384;
 int merge_slices(int nlists, int k_in) {
-  if ((long)nlists * k_in <= 8192 || k_in > 8192) return 1;
-  const int per = 8192 / k_in;
+  if ((long)nlists * k_in <= kSliceCand || k_in > kSliceCand) return 1;
+  const int per = kSliceCand / k_in;
   return (nlists + per - 1) / per;
 }
 
@@ -251,7 +253,7 @@ int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, i
   const int slices = (inter_s && inter_i) ? merge_slices(nlists, k_in) : 1;
   if (slices > 1) {
     // level 1: every slice's k_out best (local rows, id_base 0) -> [nq, slices, k_out]; level 2: those short lists
-    const int per = 8192 / k_in;
+    const int per = kSliceCand / k_in;
     hipLaunchKernelGGL((merge_kernel<int>), dim3(nq, slices), dim3(kThreads), 0, stream, scores, rows, nlists, k_in, k_out,
                        (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, (int64_t)0, inter_s, inter_i, per);
     hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, inter_s, inter_i, slices, k_out, k_out,

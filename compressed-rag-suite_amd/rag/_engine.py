@@ -73,7 +73,7 @@ class RetrievalEngine:
         self.encode = bool(encode)
         qb = int(queries_per_batch)
         self.nq_all = qb * world if queries_per_rank else qb
-        self.k_scan = nat.overfetch(self.nq_all, self.k, int(k_scan), view.n) if self.refine else self.k
+        self.k_scan = nat.overfetch(self.nq_all, self.k, int(k_scan), view.n, view.slab_type) if self.refine else self.k
         shard_w = 1
         if self.multi and not queries_per_rank and encode_shard > 1 and qb % encode_shard == 0:
             shard_w = encode_shard

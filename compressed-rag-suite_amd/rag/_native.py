@@ -236,7 +236,7 @@ def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out
     return out_scores, out_ids
 
 
-def overfetch(nq: int, top_k: int, want: int = 32, n_rows: int = 1 << 62) -> int:
+def overfetch(nq: int, top_k: int, want: int = 32, n_rows: int = 1 << 62, slab_type: int = SLAB_F16) -> int:
     """Candidates the scan fetches for the fp32 re-rank (never below top_k, never above MAX_K).
     `want` (32) on shards of >= 4 M rows, where the top scores crowd together (10 M x 384: about 1e-3 apart at rank 10) and the
     certificate holds for all but ~1e-5 of random queries with 32 candidates but only all but ~3e-4 with 16 -- an escalation
@@ -244,9 +244,11 @@ def overfetch(nq: int, top_k: int, want: int = 32, n_rows: int = 1 << 62) -> int
     escalation sweep is short, and the longer chain / tile refine / merge of 32 candidates measured 16 % of a 1.25 M-row
     shard's batch (0.301 -> 0.259 ms: one rank of an 8-GPU step).  Launches of more than 64 queries keep to 16 when top_k
     allows: the large-batch kernels (scan_wide.hip) carry a 16-slot chain, and 32 candidates would send those launches to the
-    64-query kernel once per query block."""
+    64-query kernel once per query block.  int8 slabs: 16 -- their certificate is too wide to hold at either length
+    (0.07 % / 34 % of C5's queries at 16 / 32), the empirical Recall@10 is 1.0 on 8192 queries at both, and the 32-slot chain makes the
+    issue-bound int8 kernel 6 % slower (C5 31.3 -> 33.5 k q/s)."""
     want = int(want)
-    if n_rows < 4_000_000 or (nq > 64 and top_k <= 16):
+    if n_rows < 4_000_000 or (nq > 64 and top_k <= 16) or slab_type == SLAB_I8:
         want = min(want, 16)
     return min(MAX_K, max(int(top_k), want))
 

@@ -610,7 +610,7 @@ class VectorStore:
             s, i = self._topk_large(sh, q32, slab, scales, shadow if refine else None, n, top_k)
         else:
             q16 = nat.queries_to_f16(q32, sh.slab_type)
-            k_scan = nat.overfetch(nq, top_k, self.refine_overfetch, n) if refine else top_k
+            k_scan = nat.overfetch(nq, top_k, self.refine_overfetch, n, sh.slab_type) if refine else top_k
             s, i = nat.cosine_topk(q16, slab, n, sh.dim, k_scan, slab_type=sh.slab_type, scales=scales,
                                    workspace=sh.workspace(nq, k_scan, n))
             if refine:

@@ -122,7 +122,7 @@ def test_c2_full_size(cuda):
 @pytest.mark.parametrize("n,d,nq,k,kind", [(300_000, 384, 64, 20, "f16"), (300_000, 384, 7, 32, "f16"), (300_000, 768, 64, 32, "i8"),
                                             (300_000, 128, 64, 17, "f16"), (300_000, 384, 33, 40, "f16"), (300_000, 256, 64, 64, "f16"),
                                             (160_000, 768, 64, 40, "f16"), (300_000, 768, 64, 40, "i8"), (300_000, 384, 64, 56, "f16"),
-                                            (200_000, 512, 64, 48, "f16")])
+                                            (500_000, 512, 64, 48, "f16")])
 def test_long_chain_matches_oracle_and_threshold_kernels(cuda, n, d, nq, k, kind):
     """16 < k <= 64 on streams too long for the dump form: scan_tb / scan_i8 with a 32- / 40- / 48- / 56- / 64-slot chain.  Checked against the
     oracle; test_scan_classic_gpu.py re-runs this module on the threshold kernels (CRS_SCAN_TB=0)."""
