@@ -6,7 +6,7 @@ torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
 One query BATCH through the retrieve path, everything resident in HBM:
   query encoder forward (token ids [Qb, 16] -> fp32 sentence embeddings + the scan's fp16 query block)
-  -> exact cosine scan of this rank's slab shard, over-fetching k' = 32 candidates per query
+  -> exact cosine scan of this rank's slab shard, over-fetching k' = 24 candidates per query
   -> per-workgroup list merge + tile refine -> fp32 re-rank of the k' candidates against the fp32 shadow
      of the shard (the ranking the reference's fp32 ChromaDB collection gives) WITH a per-query exactness
      certificate (csrc/exact.hip), unproven queries escalated on the device inside the same graph (fp16
@@ -61,7 +61,7 @@ WORKLOADS = {
 }
 ENC_WORKLOADS = {"enc-minilm": ("minilm", 256, 256), "enc-bge": ("bge", 64, 512)}   # (arch, chunks per batch, tokens per chunk)
 QUERY_TOKENS = 16
-K_SCAN = 32               # candidates the scan over-fetches for the fp32 re-rank (VectorStore's default refine_overfetch)
+K_SCAN = 24               # candidates the scan over-fetches for the fp32 re-rank (VectorStore's default refine_overfetch)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TF = {"f16": 2500.0, "i8": 5000.0}
 
@@ -297,7 +297,8 @@ def main():
                          "from 4 GPUs on (when N divides the batch), replicated below")
     ap.add_argument("--enc-small-lds", default="auto", choices=("auto", "on", "off"),
                     help="the encoder's <= 48 KB-of-LDS kernel forms (auto: with role lanes only)")
-    ap.add_argument("--k-scan", type=int, default=0, help="candidates the scan over-fetches for the fp32 re-rank (0: 32)")
+    ap.add_argument("--k-scan", type=int, default=0,
+                    help="candidates the scan over-fetches for the fp32 re-rank (0: the library's rule, rag/_native.py overfetch: 24 on fp16 shards of >= 4 M rows, else 16)")
     ap.add_argument("--exact", default="auto", choices=("auto", "on", "off"),
                     help="in-stream escalation of queries whose list the certificate could not prove (auto: fp16 slabs on, int8 empirical)")
     ap.add_argument("--recall-queries", type=int, default=8192,
@@ -371,7 +372,6 @@ def main():
     refine = not args.no_refine
     slab_type = nat.SLAB_I8 if slab_kind == "i8" else nat.SLAB_F16
     pd = nat.padded_dim(dim, slab_type)
-    k_scan_cfg = args.k_scan if args.k_scan > 0 else K_SCAN
 
     # ---- index build (untimed): synthetic embeddings -> slab shard (+ fp32 shadow) in HBM through the product path
     slab = torch.empty((rows, pd), dtype=torch.int8 if slab_type == nat.SLAB_I8 else torch.float16, device=dev)
@@ -426,7 +426,7 @@ def main():
 
     def make_engine(do_refine, exact):
         return RetrievalEngine(enc if not args.scan_only else None, view if do_refine else ShardView(slab, scales, None, rows, dim, slab_type, id_base),
-                               qb, QUERY_TOKENS, k, k_scan=k_scan_cfg, refine=do_refine, exact=exact, n_ctx=n_ctx, lanes=args.lanes,
+                               qb, QUERY_TOKENS, k, k_scan=K_SCAN, k_scan_exact=args.k_scan, refine=do_refine, exact=exact, n_ctx=n_ctx, lanes=args.lanes,
                                enc_lanes=args.enc_lanes, search_lanes=args.search_lanes, graphs=not args.no_graph,
                                dist=dist if multi else None, world=world, rank=rank, queries_per_rank=not strong,
                                encode_shard=(world if (strong and multi and want_shard) else 1),

@@ -55,7 +55,8 @@ __device__ __forceinline__ float wave_clean_desc(float v, int lane) {
   return v;
 }
 
-template <typename IdT>
+// REGE: candidates a thread keeps in registers on the single-pass path (32: 8192 per workgroup, 173 VGPRs; 64: 16384, 244 VGPRs)
+template <typename IdT, int REGE = 32>
 __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict__ scores,
                                                         const IdT* __restrict__ ids, int nlists,
                                                         int k_in, int k_out, size_t list_stride,
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
   // pulls its <= 64 strided candidates into registers with all loads in flight at once, so the
   // candidate set crosses the memory system exactly once (the generic path below walks it twice in
   // batches of 8 and was bound by those serial round trips).
-  constexpr int kRegE = 64;
+  constexpr int kRegE = REGE;
   const bool cached = contig && n_pass <= kRegE;
   float cs[kRegE];
   IdT ci[kRegE];
@@ -239,29 +240,44 @@ __global__ __launch_bounds__(kThreads) void merge_kernel(const float* __restrict
 }  // namespace
 
 // stage-2 layout: [nq, nlists, k_in] (a query's candidates are contiguous)
-// Slices of a two-level stage-2 merge: whole lists, at most 16384 candidates (the register-cached path: 64 per thread) per
-// workgroup -- 512 streams x 32 chain slots (C4 at k' = 32) still merge in ONE launch.
-constexpr int kSliceCand = 16384;
-int merge_slices(int nlists, int k_in) {
-  if ((long)nlists * k_in <= kSliceCand || k_in > kSliceCand) return 1;
-  const int per = kSliceCand / k_in;
+// Stage-2 merges of more than 8192 candidates per query.  Few queries (C4: 64 x 512 streams x 24 / 32 chain slots): ONE launch of
+// the 64-per-thread form (16384 candidates per workgroup) -- a second launch would cost more than the lower occupancy.  Many
+// queries (C3: 256 x 31 488 dumped representatives): two levels, slices of <= 8192 candidates on the 32-per-thread form (four
+// workgroups per CU; the 64-per-thread form measured 73 against 53 us there).
+int merge_slice_cand(int nq, int nlists, int k_in) {
+  const long m = (long)nlists * k_in;
+  return (m <= 16384 && (long)nq * ((m + 8191) / 8192) < 256) ? 16384 : 8192;
+}
+int merge_slices_for(int nq, int nlists, int k_in) {
+  const int cand = merge_slice_cand(nq, nlists, k_in);
+  if ((long)nlists * k_in <= cand || k_in > cand) return 1;
+  const int per = cand / k_in;
+  return (nlists + per - 1) / per;
+}
+int merge_slices(int nlists, int k_in) {   // upper bound over nq (workspace sizing): the 8192-candidate slicing
+  if ((long)nlists * k_in <= 8192 || k_in > 8192) return 1;
+  const int per = 8192 / k_in;
   return (nlists + per - 1) / per;
 }
 
 int merge_launch_i32(const float* scores, const int* rows, int nlists, int nq, int k_in, int k_out,
                      int64_t id_base, float* out_scores, int64_t* out_ids, float* inter_s, int64_t* inter_i, hipStream_t stream) {
-  const int slices = (inter_s && inter_i) ? merge_slices(nlists, k_in) : 1;
+  const int slices = (inter_s && inter_i) ? merge_slices_for(nq, nlists, k_in) : 1;
   if (slices > 1) {
     // level 1: every slice's k_out best (local rows, id_base 0) -> [nq, slices, k_out]; level 2: those short lists
-    const int per = kSliceCand / k_in;
+    const int per = merge_slice_cand(nq, nlists, k_in) / k_in;
     hipLaunchKernelGGL((merge_kernel<int>), dim3(nq, slices), dim3(kThreads), 0, stream, scores, rows, nlists, k_in, k_out,
                        (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, (int64_t)0, inter_s, inter_i, per);
     hipLaunchKernelGGL((merge_kernel<int64_t>), dim3(nq), dim3(kThreads), 0, stream, inter_s, inter_i, slices, k_out, k_out,
                        (size_t)k_out, (size_t)k_out, (size_t)slices * k_out, id_base, out_scores, out_ids, slices);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL((merge_kernel<int>), dim3(nq), dim3(kThreads), 0, stream, scores, rows, nlists,
-                     k_in, k_out, (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids, nlists);
+  if ((long)nlists * k_in > 8192 && merge_slice_cand(nq, nlists, k_in) == 16384)
+    hipLaunchKernelGGL((merge_kernel<int, 64>), dim3(nq), dim3(kThreads), 0, stream, scores, rows, nlists,
+                       k_in, k_out, (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids, nlists);
+  else
+    hipLaunchKernelGGL((merge_kernel<int>), dim3(nq), dim3(kThreads), 0, stream, scores, rows, nlists,
+                       k_in, k_out, (size_t)k_in, (size_t)k_in, (size_t)nlists * k_in, id_base, out_scores, out_ids, nlists);
   return (int)hipGetLastError();
 }
 

@@ -264,6 +264,7 @@ int launch_tb_k(const ScanArgs& a, int slots, hipStream_t stream) {
     // instead of the threshold kernels.  32 slots (64 registers) fit beside the query fragments of every row length at two
     // waves per SIMD; 64 slots only for 256- / 384-element rows (they spill from 512 on).  10 M x 384, 64 queries, k = 17 / 32:
     // scan 2.36 / 2.13 ms on the threshold kernels -> 1.23 ms, whole search 2.09 / 2.16 -> 1.31 / 1.32.
+    case 24: if constexpr (NW == 4) return launch_tb<D, TR, NW, 24>(a, stream); else return -1;   // the store's over-fetch on large shards
     case 32: if constexpr (NW == 4) return launch_tb<D, TR, NW, 32>(a, stream); else return -1;
     // register budgets checked by tools/check_resources.py (no plan-selectable instantiation may touch scratch): 64 slots
     // fit 256-element rows only (384: 20 bytes / lane of scratch), 56 / 48 slots 384-element rows, 48 slots 512 / 640, 40 slots
@@ -307,6 +308,7 @@ int scan_tb_wg_per_cu(int pdim, int nw) {
 // chain length for 16 < k <= 64 on long streams (0: none -- the threshold kernels take the search)
 int scan_tb_long_chain_slots(int pdim, int nw, int k) {
   if (nw != 4 || k <= 16 || k > 64) return 0;
+  if (k <= 24) return 24;
   if (k <= 32) return 32;
   if (pdim == 256) return 64;
   if (pdim == 384) return k <= 48 ? 48 : (k <= 56 ? 56 : 0);

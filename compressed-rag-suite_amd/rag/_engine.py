@@ -48,7 +48,7 @@ class _Ctx:
 
 
 class RetrievalEngine:
-    def __init__(self, encoder, view: ShardView, queries_per_batch: int, seq: int, top_k: int, *, k_scan: int = 32,
+    def __init__(self, encoder, view: ShardView, queries_per_batch: int, seq: int, top_k: int, *, k_scan: int = 24, k_scan_exact: int = 0,
                  refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 8, lanes: str = "auto",
                  enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
                  queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True,
@@ -73,7 +73,9 @@ class RetrievalEngine:
         self.encode = bool(encode)
         qb = int(queries_per_batch)
         self.nq_all = qb * world if queries_per_rank else qb
-        self.k_scan = nat.overfetch(self.nq_all, self.k, int(k_scan), view.n, view.slab_type) if self.refine else self.k
+        # candidates the scan fetches: nat.overfetch's rule from the wanted length, or (k_scan_exact > 0: A/B runs) exactly that many
+        self.k_scan = (min(nat.MAX_K, max(self.k, int(k_scan_exact))) if k_scan_exact > 0 else
+                       nat.overfetch(self.nq_all, self.k, int(k_scan), view.n, view.slab_type)) if self.refine else self.k
         shard_w = 1
         if self.multi and not queries_per_rank and encode_shard > 1 and qb % encode_shard == 0:
             shard_w = encode_shard

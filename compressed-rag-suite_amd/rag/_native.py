@@ -236,12 +236,13 @@ def refine_f32(q32, shadow, n_rows: int, id_base: int, cand_ids, k_out: int, out
     return out_scores, out_ids
 
 
-def overfetch(nq: int, top_k: int, want: int = 32, n_rows: int = 1 << 62, slab_type: int = SLAB_F16) -> int:
+def overfetch(nq: int, top_k: int, want: int = 24, n_rows: int = 1 << 62, slab_type: int = SLAB_F16) -> int:
     """Candidates the scan fetches for the fp32 re-rank (never below top_k, never above MAX_K).
-    `want` (32) on shards of >= 4 M rows, where the top scores crowd together (10 M x 384: about 1e-3 apart at rank 10) and the
-    certificate holds for all but ~1e-5 of random queries with 32 candidates but only all but ~3e-4 with 16 -- an escalation
-    there costs a second sweep of the whole shard.  16 on smaller shards: the same gaps are wider (fewer rows in the tail), an
-    escalation sweep is short, and the longer chain / tile refine / merge of 32 candidates measured 16 % of a 1.25 M-row
+    `want` (24) on shards of >= 4 M rows, where the top scores crowd together (10 M x 384: about 1e-3 apart at rank 10; the gap
+    from rank 10 to rank 24 is ~9e-3 against a certificate bound of ~6e-4): all 8192 benchmark queries certify with 24 as with 32
+    candidates, while with 16 about 3e-4 of them would escalate -- a second sweep of the whole shard each.  Same box, C4 batch:
+    1.408 / 1.432 / 1.451 ms at 16 / 24 / 32 (chain slots, tile refine and merge grow with the length).  16 on smaller shards: the
+    same gaps are wider (fewer rows in the tail), an escalation sweep is short, and 32 candidates measured 16 % of a 1.25 M-row
     shard's batch (0.301 -> 0.259 ms: one rank of an 8-GPU step).  Launches of more than 64 queries keep to 16 when top_k
     allows: the large-batch kernels (scan_wide.hip) carry a 16-slot chain, and 32 candidates would send those launches to the
     64-query kernel once per query block.  int8 slabs: 16 -- their certificate is too wide to hold at either length

@@ -11,7 +11,7 @@ New, additive surface (all keys absent from the reference config.json default so
   ``search_batch``            many queries per launch
   ``index_dtype``             'fp16' (default) | 'int8' (per-row scale)
   ``refine_fp32``             (default ON) keep an fp32 shadow of the rows (4 x dim bytes per row beside the fp16 / int8
-                              slab), over-fetch ``refine_overfetch`` (32) candidates and re-rank them in fp32: the ranking an
+                              slab), over-fetch ``refine_overfetch`` (24; 16 on shards below 4 M rows) candidates and re-rank them in fp32: the ranking an
                               fp32 store such as the reference's returns (rag/indexing.py:114-119,171-176).  False = the
                               plain fp16 / int8 ranking, no shadow
   ``refine_exact``            'auto' (default) | True | False: every re-ranked list carries a per-query PROOF that it is the
@@ -20,7 +20,7 @@ New, additive surface (all keys absent from the reference config.json default so
                               chunks) are escalated on the device (crs::escalate_exact: one more sweep lists every row that
                               can still rank, fp32 re-rank of the list).  'auto' escalates on fp16 slabs; on int8 slabs the
                               bound (~1e-2 for 768-d rows) is wider than typical score gaps, so the certificate rarely
-                              holds at k' = 32 and escalating would cost a second sweep for most batches: int8 stays
+                              holds and escalating would cost a second sweep for most batches: int8 stays
                               EMPIRICAL (re-rank only) unless refine_exact=True.  ``last_exactness`` reports the counts
   ``num_gpus`` / ``devices``  ONE process driving N devices: contiguous row shards, per-device scans, partial lists
                               copied to the first device and merged there -- RAGPipeline stays one object
@@ -290,7 +290,7 @@ class VectorStore:
             raise ValueError(f"index_dtype must be 'fp16' or 'int8', got {self.index_dtype!r}")
         refine = config.get('refine_fp32', 'auto')
         self.refine_fp32 = True if refine == 'auto' else bool(refine)
-        self.refine_overfetch = int(config.get('refine_overfetch', 32))
+        self.refine_overfetch = int(config.get('refine_overfetch', 24))
         exact = config.get('refine_exact', 'auto')
         if exact not in ('auto', True, False):
             raise ValueError(f"refine_exact must be 'auto', True or False, got {exact!r}")

@@ -172,7 +172,7 @@ def test_store_default_config_returns_the_fp32_ranking(cuda, dtype):
     from rag.indexing import VectorStore
     cfg = {"collection_name": "exact"} if dtype == "fp16" else {"collection_name": "exact8", "index_dtype": "int8", "refine_exact": True}
     store = VectorStore(cfg)
-    assert store.refine_fp32 is True and store.refine_overfetch == 32      # (16 of them on shards below 4 M rows: nat.overfetch)
+    assert store.refine_fp32 is True and store.refine_overfetch == 24      # (16 of them on shards below 4 M rows: nat.overfetch)
     rng = np.random.default_rng(11)
     n, d = 120_000, 384
     emb = rng.standard_normal((n, d)).astype(np.float32)

@@ -2,9 +2,10 @@
 """gpurun_out/r03_* (tools/make_profiles_r03.sh) -> profiles/r03_*: bench lines, kernel-stats tables, PMC / SQ summaries.
 HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KiB and, on gfx950, HALF the bytes of a wide coalesced streaming
 read -> read bytes = FETCH_SIZE * 1024 * 2."""
-import collections, csv, glob, json, os, re, shutil, subprocess
+import collections, csv, glob, json, os, re, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-go, pr, tag = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles"), "r03"
+# usage: collect_profiles_r03.py [OUT_DIR]   (default profiles/; on the GPU box: gpurun_out/r03_profiles, the raw traces are then deleted)
+go, pr, tag = os.path.join(root, "gpurun_out"), (os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else os.path.join(root, "profiles")), "r03"
 os.makedirs(pr, exist_ok=True)
 csv.field_size_limit(1 << 30)
 for f in glob.glob(os.path.join(go, f"{tag}_bench_*.json")):
@@ -35,7 +36,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in found[-1:]:
         for r in csv.DictReader(open(f)):
             m = scan_pat.search(r["Kernel_Name"])
-            if not m or r["Counter_Name"] != c or ",32>" not in m.group(1): continue     # the timed plan (k' = 32), not the k' = 10 comparison launch
+            if not m or r["Counter_Name"] != c or re.search(r", ?10>$", m.group(1)): continue     # the timed plan, not the k' = 10 comparison launch
             name = m.group(1)
             vals.append(float(r["Counter_Value"])); ns.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     if len(vals) > 4: vals, ns = vals[2:], ns[2:]

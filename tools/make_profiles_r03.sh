@@ -44,3 +44,7 @@ for set in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_AN
 done
 python3 tools/bench_gemm.py 4096 4096 4096 0 32768 2304 768 0 32768 3072 768 1 32768 768 3072 2 32768 768 768 2 65536 1536 384 1 65536 1152 384 0 65536 384 1536 2 4096 2304 768 0 4096 3072 768 1 > $O/${TAG}_gemm_tflops.txt 2>&1
 echo "gemm done"
+# summarise ON the box (gpurun copies back at most 64 MiB: the raw traces stay here), keep logs + summaries only
+python3 tools/collect_profiles_r03.py $O/${TAG}_profiles > $O/${TAG}_collect.log 2>&1 || tail -5 $O/${TAG}_collect.log
+rm -rf $O/${TAG}_stats_* $O/${TAG}_pmc_* $O/${TAG}_sq[12]_* $O/${TAG}_gemm_sq[12] 
+ls $O/${TAG}_profiles | head -50
