@@ -39,6 +39,8 @@ int device_cus() {
 
 
 constexpr int kW1MaxDump = 256;
+// streams shorter than this many tiles keep the static stride (1.25 M x 384 rows = 76 tiles per stream measured no gain)
+constexpr int kDynMinRounds = 96;
 
 struct Plan {
   int pdim, tile_rows, n_tiles, nwg, kp;   // nwg = tile streams (workgroups per query block)
@@ -61,6 +63,20 @@ bool tb_long_chain() {   // CRS_SCAN_LONG_CHAIN=0: 16 < k <= 64 on long streams 
   static int v = -1;
   if (v < 0) { const char* e = getenv("CRS_SCAN_LONG_CHAIN"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
+}
+// Dynamic tile schedule of the chain-mode tile-best scan (scan_tb.hip): percent of the tiles handed out through the counter and
+// tiles per ticket.  Defaults 85 % in granules of 8 (C4 beside the encoder lanes: 44.9 -> 47.2 k q/s on one box; 20 / 50 / 95 / 100 %
+// and granules of 4 / 16 measured within 1 % of that or worse; a ticket per tile is bound by the ~90 M atomics/s one address
+// takes).  CRS_TB_DYN=0 restores the static stride.  Read per call: tools/tb_dyn_check.py switches it inside one process.
+int tb_dyn_percent() {
+  const char* e = getenv("CRS_TB_DYN");
+  const int v = e ? atoi(e) : 85;
+  return v < 0 ? 0 : v > 100 ? 100 : v;
+}
+int tb_dyn_granule() {
+  const char* e = getenv("CRS_TB_DYN_G");
+  const int v = e ? atoi(e) : 8;
+  return v >= 16 ? 16 : v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1;
 }
 bool tb_enabled() {   // CRS_SCAN_TB=0: always use the threshold/compaction kernel for <= 64 queries (A/B runs, tests)
   static int v = -1;
@@ -246,6 +262,23 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.k = k;
   a.nwg = p.nwg;
   a.nqb = p.nqb;
+  a.ticket = nullptr;
+  a.t_dyn = p.n_tiles;
+  a.dyn_mask = 0;
+  if (slab_type == CRS_SLAB_F16 && p.tb_nw && p.tb_slots > 0 && p.nqb == 1 && !share) {
+    // long chain-mode streams: the last tb_dyn_percent() of the tiles are drawn from a counter (scan_tb.hip), which lives in the
+    // (otherwise unused) shared-threshold words at the head of the workspace; scan_launch_tb zeroes it in stream order ahead of the scan
+    const int rounds = p.n_tiles / p.nwg, pct = tb_dyn_percent();
+    const char* me = getenv("CRS_TB_DYN_MIN");   // tests: dynamic schedule on short streams too
+    const int min_rounds = me ? atoi(me) : kDynMinRounds;
+    if (pct > 0 && rounds >= (min_rounds < 4 ? 4 : min_rounds)) {
+      int stat = (int)((int64_t)rounds * (100 - pct) / 100);
+      if (stat < 2) stat = 2;
+      a.t_dyn = stat * p.nwg;
+      a.ticket = tau;
+      a.dyn_mask = tb_dyn_granule() - 1;
+    }
+  }
   const int e = p.w1_qg ? crs::scan_launch_w1(a, p.pdim, st)
                 : p.wide_nw ? crs::scan_launch_wide(a, p.pdim, p.wide_nw, st)
                 
@@ -417,6 +450,28 @@ int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type
   else snprintf(name, sizeof name, "scan_f16_kernel<%d,%d,%d>", p.pdim, p.tile_rows, k <= 16 ? 16 : 32);
   snprintf(buf, cap, "%s streams=%d qblocks=%d kp=%d + merge%s", name, p.nwg, p.nqb, p.kp, p.group_best ? " + refine" : "");
   return CRS_OK;
+}
+
+int crs_stream_create_cu_masked(int first_cu, int n_cus, void** stream_out) {
+  if (!stream_out || n_cus <= 0 || first_cu < 0) return fail(CRS_EINVAL, "bad CU range / null output");
+  const int cus = device_cus();
+  if (cus <= 0) return fail(CRS_EHIP, "no HIP device available%s");
+  if (first_cu + n_cus > cus) return fail(CRS_EINVAL, "CU range exceeds the device");
+  const int words = (cus + 31) / 32;
+  uint32_t mask[16] = {0};
+  if (words > 16) return fail(CRS_EINVAL, "device has more than 512 CUs");
+  for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+  if (e != hipSuccess) return hip_fail(e, "hipExtStreamCreateWithCUMask");
+  *stream_out = (void*)st;
+  return CRS_OK;
+}
+
+int crs_stream_destroy(void* stream) {
+  if (!stream) return CRS_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? CRS_OK : hip_fail(e, "hipStreamDestroy");
 }
 
 int crs_time_cosine_topk(const void* q16_dev, int nq, int dim, int slab_type, const void* slab_dev,

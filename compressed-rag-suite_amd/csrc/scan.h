@@ -22,6 +22,9 @@ struct ScanArgs {
   int kp;                 // slots per (query, workgroup) partial list (capi.hip make_plan: k, tiles per stream, or chain slots)
   int nwg;                // tile streams (workgroups per query block)
   int nqb;                // query blocks (64, 128 or 256 queries each); the grid is nqb * nwg workgroups (scan_common.h: grid mapping)
+  unsigned* ticket;       // scan_tb.hip chain mode: tiles >= t_dyn are handed out through this counter (zero at launch); else nullptr
+  int t_dyn;              //   first dynamically scheduled tile (a multiple of nwg, >= 2 nwg); n_tiles when the schedule is static
+  int dyn_mask;           //   a ticket stands for dyn_mask + 1 consecutive tiles (a power of two)
 };
 
 // scan_refine.hip: re-open the k winning tiles (16, 32 or 64 rows each) per query, re-score, rank

@@ -108,6 +108,16 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   const int tstep = nwg, tend = a.n_tiles;
   int t = stream;
 #endif
+  // Tile order.  Static part: tiles stream, stream + nwg, ... below t_dyn.  Dynamic part (chain mode, long streams): granules of
+  // dyn_mask + 1 consecutive tiles from t_dyn + ticket * (dyn_mask + 1), the ticket drawn from a device-wide counter (one address
+  // takes ~90 M atomics/s on this part: a ticket per tile would be the bottleneck) -- a workgroup that was held up (an encoder kernel on its CU, a
+  // slower HBM channel) then simply draws fewer tiles instead of making the whole launch wait for its fixed share.  The tile
+  // AFTER the look-ahead tile is requested at the top of an iteration (thread 0, one atomic) and handed to the workgroup through
+  // LDS behind the iteration's barrier: a ticket has a whole tile time (~2 us) to come back.  Any assignment gives the same lists
+  // after the merge: a workgroup still sees its tiles in increasing order (ties keep the earlier tile, as before).
+  __shared__ int sh_next[2];
+  const int t_dyn = K > 0 ? a.t_dyn : a.n_tiles;
+  int tn = t + tstep;     // the look-ahead tile (t_dyn >= 2 nwg: static for the first iteration)
   dma_tile(t, 0);   // before the query fragments are fetched: the two latencies overlap
   const int lr = lane & 15, kq = lane >> 4;
   const int qi = qbase + lr;
@@ -161,8 +171,23 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   int cur = 0, it = 0;
   // one iteration: tile t sits in LDS buffer `cur`; tile t + nwg streams into the other buffer while t is multiplied
   while (t < tend) {
-    const bool has_next = t + tstep < tend;
-    if (has_next) dma_tile(t + tstep, cur ^ 1);
+    const bool has_next = tn < tend;
+    if (has_next) dma_tile(tn, cur ^ 1);
+    // the tile after tn: static stride, the next tile of tn's granule, or -- tn is the last static tile / the last tile of its
+    // granule -- the first tile of the granule the counter hands out (wave-uniform)
+    const bool in_dyn = K > 0 && tn >= t_dyn;
+    const bool draw = K > 0 && a.ticket != nullptr && (in_dyn ? ((tn - t_dyn) & a.dyn_mask) == a.dyn_mask : tn + tstep >= t_dyn);
+    unsigned tk = 0;
+    if constexpr (K > 0) {
+      // one lane draws; written as asm under a hand-set exec mask: hipcc's atomicAdd waits for the returned value on the spot
+      // (its wave-aggregation rewrite reads it at once), i.e. for the look-ahead transfer issued just above as well -- transfer
+      // and multiplication of the dynamic tiles would no longer overlap.  The value is first read behind the vmcnt(0) below.
+      const unsigned mask = __builtin_amdgcn_readfirstlane((draw && has_next && wave == 0) ? 1u : 0u);   // lane 0 of wave 0, or nobody
+      unsigned long long keep;
+      const unsigned zero = 0u, one = 1u;
+      asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %3, %4, %5 sc0\n\ts_mov_b64 exec, %1"
+                   : "+v"(tk), "=&s"(keep) : "s"(mask), "v"(zero), "v"(one), "s"(a.ticket) : "memory");
+    }
     WP_LAP(1);   // look-ahead issue
 #if defined(CRS_TB_EXPERIMENT) && CRS_TB_EXPERIMENT <= 2   /* tools/scan_tb_probe.hip: timing-only builds (1: no MFMA / selection, 3: fragment reads without MFMA, 4: MFMA without fragment reads) */
     if (false) {
@@ -206,15 +231,22 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
       }
     }
     WP_LAP(4);   // selection
+    int tnn = in_dyn ? tn + 1 : tn + tstep;
     if (has_next) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      WP_LAP(5);   // wait for the look-ahead tile
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk) : : "memory");
+      WP_LAP(5);   // wait for the look-ahead tile (and for the ticket)
+      if (K > 0 && draw && tid == 0) sh_next[it & 1] = t_dyn + (int)tk * (a.dyn_mask + 1);
       __syncthreads();
       WP_LAP(7);   // barrier
+      if (K > 0 && draw) {   // two slots: iteration it + 1 writes the other one
+        tnn = __builtin_amdgcn_readfirstlane(sh_next[it & 1]);
+        tnn = (unsigned)tnn < (unsigned)tend ? tnn : tend;   // a poisoned counter must not become an address
+      }
     }
     cur ^= 1;
     ++it;
-    t += tstep;
+    t = tn;
+    tn = tnn;
   }
   if (wave_active) {
     if constexpr (K == 0) {
@@ -238,6 +270,10 @@ __global__ __launch_bounds__(NW * 64, (TbCfg<D, TR, NW>::kWgpc * NW) / 4) void s
   WP_STORE(NW);
 }
 
+__global__ void tb_zero_ticket_kernel(unsigned* ticket) {
+  if (threadIdx.x < 4) ticket[threadIdx.x] = 0u;
+}
+
 template <int D, int TR, int NW, int K>
 int launch_tb(const ScanArgs& a, hipStream_t stream) {
   using C = TbCfg<D, TR, NW>;
@@ -249,6 +285,9 @@ int launch_tb(const ScanArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     done = true;
   }
+  // the ticket counter is zeroed by a kernel of our own, in stream order: a kernel node in a captured graph like the scan itself
+  // (a hipMemsetAsync node gave correct lists too, but split the graph's event timing)
+  if (a.ticket) hipLaunchKernelGGL(tb_zero_ticket_kernel, dim3(1), dim3(64), 0, stream, a.ticket);
   hipLaunchKernelGGL(kernel, dim3(a.nqb * a.nwg), dim3(NW * 64), C::kLds, stream, a);
   return (int)hipGetLastError();
 }

@@ -23,6 +23,7 @@ of >= 512 MB per batch, where it measured faster, and keep
 """
 from __future__ import annotations
 
+import os
 import sys
 from dataclasses import dataclass
 from typing import List, Optional
@@ -52,7 +53,7 @@ class RetrievalEngine:
                  refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 8, lanes: str = "auto",
                  enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
                  queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True,
-                 enc_small_lds="auto"):
+                 enc_small_lds="auto", enc_cus: int = 0):
         """queries_per_batch: the GLOBAL batch every rank searches (strong scaling), or with ``queries_per_rank`` the queries
         THIS rank contributes (weak scaling: the scan then sees world x that many).  encode_shard = W > 1: each rank encodes
         Qb / W queries and the embeddings are all-gathered first (two collectives per batch instead of one).
@@ -99,7 +100,14 @@ class RetrievalEngine:
             # second search lane would overlap consecutive scans (1 - 2 % on 10 M rows) and make per-kernel durations meaningless
             self.n_enc = enc_lanes if enc_lanes > 0 else 2
             self.n_srch = search_lanes if search_lanes > 0 else 1
-            self.enc_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_enc)]
+            self.enc_cus = int(os.environ.get("CRS_ENC_CUS", enc_cus))
+            if self.enc_cus > 0:
+                # encoder lanes confined to a few CUs each (lane i: CUs [i * enc_cus, (i + 1) * enc_cus)): the 38-launch chain is
+                # latency-bound and has a whole scan (two with two lanes) to finish in, so it does not need the chip -- and the
+                # sweep's dynamic tile schedule (scan_tb.hip) gives the workgroups on those CUs fewer tiles
+                self.enc_streams = [nat.cu_masked_stream(i * self.enc_cus, self.enc_cus, self.dev) for i in range(self.n_enc)]
+            else:
+                self.enc_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_enc)]
             self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_srch)]
         else:
             self.n_enc = self.n_srch = self.n_ctx

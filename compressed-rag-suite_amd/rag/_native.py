@@ -52,6 +52,8 @@ _SIGNATURES = {
     "crs_wire_scores_offset": (c_size_t, [c_int, c_int]),
     "crs_merge_topk_wire": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "crs_scan_plan_describe": (c_int, [c_int, c_int, c_int, c_int64, c_int, ctypes.c_char_p, c_size_t]),
+    "crs_stream_create_cu_masked": (c_int, [c_int, c_int, POINTER(c_void_p)]),
+    "crs_stream_destroy": (c_int, [c_void_p]),
     "crs_time_cosine_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
                                      c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                                      POINTER(c_float), POINTER(c_float)]),
@@ -315,6 +317,15 @@ def merge_topk_wire(gathered, nlists: int, nq: int, k_in: int, k_out: int, out_s
     with _translate():
         ops().merge_topk_wire_out(gathered, int(nlists), int(nq), int(k_in), int(k_out), out_s, out_i)
     return out_s, out_i
+
+
+def cu_masked_stream(first_cu: int, n_cus: int, device=None):
+    """A torch stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (crs_stream_create_cu_masked).  The HIP stream
+    lives as long as the process (a handful per engine)."""
+    import torch
+    out = c_void_p(0)
+    check(load().crs_stream_create_cu_masked(int(first_cu), int(n_cus), byref(out)))
+    return torch.cuda.ExternalStream(int(out.value), device=device)
 
 
 def scan_plan_describe(nq: int, dim: int, k: int, n_rows: int, slab_type: int = SLAB_F16) -> str:

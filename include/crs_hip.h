@@ -148,6 +148,14 @@ int crs_merge_topk_wire(const void* wire_dev, int nlists, int nq, int k_in, int 
  * For bench.py / profiles only; writes at most `cap` bytes including the terminator. */
 int crs_scan_plan_describe(int nq, int dim, int k, int64_t n_rows, int slab_type, char* buf, size_t cap);
 
+/* A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask; on this part consecutive
+ * mask bits go round the XCDs).  The throughput engine (rag/_engine.py) gives its query-encoder lanes such streams: the latency-bound
+ * 38-launch encoder chain then shares a few CUs with the corpus sweep instead of touching all of them, and the sweep's dynamic tile
+ * schedule routes around those CUs.  No reference counterpart (the reference runs one query at a time on one stream).
+ * Destroy with crs_stream_destroy. */
+int crs_stream_create_cu_masked(int first_cu, int n_cus, void** stream_out);
+int crs_stream_destroy(void* stream);
+
 /* Timing hook for bench.py: runs `iters` back-to-back crs_cosine_topk launches bracketed by
  * hipEvents on `stream` and returns the mean milliseconds of ONE launch pair (scan + merge)
  * in *ms_total and of the scan kernel alone in *ms_scan. */
