@@ -265,9 +265,11 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
   a.ticket = nullptr;
   a.t_dyn = p.n_tiles;
   a.dyn_mask = 0;
-  if (slab_type == CRS_SLAB_F16 && p.tb_nw && p.tb_slots > 0 && p.nqb == 1 && !share) {
-    // long chain-mode streams: the last tb_dyn_percent() of the tiles are drawn from a counter (scan_tb.hip), which lives in the
-    // (otherwise unused) shared-threshold words at the head of the workspace; scan_launch_tb zeroes it in stream order ahead of the scan
+  if (((slab_type == CRS_SLAB_F16 && p.tb_nw) || (slab_type == CRS_SLAB_I8 && p.i8_tb && p.pdim <= 768)) && p.tb_slots > 0 && p.nqb == 1 && !share) {
+    // (int8 rows of 1024 elements stay static: those instantiations spill, and the ticket's register must not travel through scratch
+    // while its value is in flight)
+    // long chain-mode streams: the last tb_dyn_percent() of the tiles are drawn from a counter (scan_tb.hip, scan_i8.hip), which lives in the
+    // (otherwise unused) shared-threshold words at the head of the workspace and is zeroed in stream order ahead of the scan
     const int rounds = p.n_tiles / p.nwg, pct = tb_dyn_percent();
     const char* me = getenv("CRS_TB_DYN_MIN");   // tests: dynamic schedule on short streams too
     const int min_rounds = me ? atoi(me) : kDynMinRounds;
@@ -277,6 +279,8 @@ static int run_scan(const Plan& p, const void* q16, int nq, int slab_type, const
       a.t_dyn = stat * p.nwg;
       a.ticket = tau;
       a.dyn_mask = tb_dyn_granule() - 1;
+      const int ze = crs::scan_ticket_zero(a.ticket, st);
+      if (ze) return ze;
     }
   }
   const int e = p.w1_qg ? crs::scan_launch_w1(a, p.pdim, st)

@@ -47,6 +47,7 @@ int scan_launch_i8(const ScanArgs& a, int pdim, int slots, hipStream_t stream);
 int scan_tb_wg_per_cu(int pdim, int nw);
 bool scan_tb_has_8_waves(int pdim);
 int scan_launch_tb(const ScanArgs& a, int pdim, int nw, int slots, hipStream_t stream);
+int scan_ticket_zero(unsigned* ticket, hipStream_t stream);   // ScanArgs::ticket := 0, in stream order (scan_tb.hip / scan_i8.hip chain modes)
 int scan_tb_long_chain_slots(int pdim, int nw, int k);   // chain length for 16 < k <= 64 on long streams (0: none)
 int scan_i8_long_chain_slots(int pdim, int k);
 // scan_wide.hip: 65+ queries per launch, k <= 16, fp16 slabs

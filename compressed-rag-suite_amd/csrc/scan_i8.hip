@@ -111,12 +111,16 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
     }
   };
   // wait for the look-ahead tile and its scales (in LDS once vmcnt says so)
+  unsigned tk = 0;   // the ticket in flight (dynamic tile schedule, as scan_tb.hip: chain modes on long streams)
   auto park_tile = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WP_LAP(5);   // wait for the look-ahead tile
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk) : : "memory");
+    WP_LAP(5);   // wait for the look-ahead tile (and the ticket)
   };
 
   int t = CRS_STREAM;
+  const int t_dyn = TBK > 0 ? a.t_dyn : a.n_tiles;
+  int tn = t + nwg;
+  int* sh_next = reinterpret_cast<int*>(sc_lds + 2 * TR * 4);   // two slots behind the row-scale slots
   load_tile(t, 0);
 
   // ---- this wave's queries -> 16-bit fixed point -> two int8 digit planes, resident in VGPRs.
@@ -191,12 +195,23 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
   WP_LAP(0);   // prologue
 
   int cur = 0;
-  for (; t < a.n_tiles; t += nwg) {
+  while (t < a.n_tiles) {
     f32x4 sc_use[C::kRt];
 #pragma unroll
     for (int rt = 0; rt < C::kRt; ++rt)   // this lane's rows 16 rt + 4 kq .. + 3
       sc_use[rt] = *reinterpret_cast<const f32x4*>(sc_lds + cur * (TR * 4) + (rt * 16 + kq * 4) * 4);
-    if (t + nwg < a.n_tiles) load_tile(t + nwg, cur ^ 1);
+    const bool has_next = tn < a.n_tiles;
+    if (has_next) load_tile(tn, cur ^ 1);
+    const bool in_dyn = TBK > 0 && tn >= t_dyn;
+    const bool draw = TBK > 0 && a.ticket != nullptr && (in_dyn ? ((tn - t_dyn) & a.dyn_mask) == a.dyn_mask : tn + nwg >= t_dyn);
+    if constexpr (TBK > 0) {   // one lane draws the granule after tn's (scan_tb.hip explains the asm form)
+      const unsigned mask = __builtin_amdgcn_readfirstlane((draw && has_next && wave == 0) ? 1u : 0u);
+      unsigned long long keep;
+      const unsigned zero = 0u, one = 1u;
+      tk = 0;
+      asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %3, %4, %5 sc0\n\ts_mov_b64 exec, %1"
+                   : "+v"(tk), "=&s"(keep) : "s"(mask), "v"(zero), "v"(one), "s"(a.ticket) : "memory");
+    }
     WP_LAP(1);   // look-ahead issue
     if (tau_pub) {
       tg = __hip_atomic_load(tau_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -252,10 +267,18 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
       asm volatile("" : "+v"(x));
       tau = fmaxf(tau, foreign_tau(x));
     }
+    if (TBK > 0 && draw && has_next && tid == 0) sh_next[it & 1] = t_dyn + (int)tk * (a.dyn_mask + 1);
     __syncthreads();
     WP_LAP(7);   // barrier
+    int tnn = in_dyn ? tn + 1 : tn + nwg;
+    if (TBK > 0 && draw && has_next) {
+      tnn = __builtin_amdgcn_readfirstlane(sh_next[it & 1]);
+      tnn = (unsigned)tnn < (unsigned)a.n_tiles ? tnn : a.n_tiles;   // a poisoned counter must not become an address
+    }
     cur ^= 1;
     ++it;
+    t = tn;
+    tn = tnn;
   }
   if (wave_active) {
     if constexpr (TBK < 0) {
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_i8_kernel(const ScanArgs a) 
 template <int D, int TR, int L, int TBK>
 int launch_i8(const ScanArgs& a, hipStream_t stream) {
   using C = CfgI8<D, TR, L>;
-  constexpr int lds = (TBK < 0 ? C::kLds : 2 * C::kTileBytes) + 2 * TR * 4;   // + the row-scale slots
+  constexpr int lds = (TBK < 0 ? C::kLds : 2 * C::kTileBytes) + 2 * TR * 4 + 16;   // + the row-scale slots + the next-tile slots
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<D, TR, L, TBK>),

@@ -285,9 +285,6 @@ int launch_tb(const ScanArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     done = true;
   }
-  // the ticket counter is zeroed by a kernel of our own, in stream order: a kernel node in a captured graph like the scan itself
-  // (a hipMemsetAsync node gave correct lists too, but split the graph's event timing)
-  if (a.ticket) hipLaunchKernelGGL(tb_zero_ticket_kernel, dim3(1), dim3(64), 0, stream, a.ticket);
   hipLaunchKernelGGL(kernel, dim3(a.nqb * a.nwg), dim3(NW * 64), C::kLds, stream, a);
   return (int)hipGetLastError();
 }
@@ -357,6 +354,13 @@ int scan_tb_long_chain_slots(int pdim, int nw, int k) {
 }
 
 // slots = 0: dump mode (kp = tiles per stream); else chain mode with that many slots (kp = slots)
+// the ticket counter is zeroed by a kernel of our own, in stream order: a kernel node in a captured graph like the scan itself
+// (a hipMemsetAsync node gave correct lists too, but split the graph's event timing)
+int scan_ticket_zero(unsigned* ticket, hipStream_t stream) {
+  hipLaunchKernelGGL(tb_zero_ticket_kernel, dim3(1), dim3(64), 0, stream, ticket);
+  return (int)hipGetLastError();
+}
+
 int scan_launch_tb(const ScanArgs& a, int pdim, int nw, int slots, hipStream_t stream) {
   switch (pdim) {
     case 128: return launch_tb_d<128, 32>(a, nw, slots, stream);

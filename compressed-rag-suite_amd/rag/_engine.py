@@ -48,12 +48,16 @@ class _Ctx:
     """Buffers of one in-flight query batch (a batch touches nothing outside its _Ctx + read-only state)."""
 
 
+class _Group:
+    """Buffers of one encoder forward: the token / embedding blocks of G consecutive batches (G = 1: of one batch)."""
+
+
 class RetrievalEngine:
     def __init__(self, encoder, view: ShardView, queries_per_batch: int, seq: int, top_k: int, *, k_scan: int = 24, k_scan_exact: int = 0,
                  refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 8, lanes: str = "auto",
                  enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
                  queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True,
-                 enc_small_lds="auto", enc_cus: int = 0):
+                 enc_small_lds="auto", enc_cus: int = 0, encode_group="auto"):
         """queries_per_batch: the GLOBAL batch every rank searches (strong scaling), or with ``queries_per_rank`` the queries
         THIS rank contributes (weak scaling: the scan then sees world x that many).  encode_shard = W > 1: each rank encodes
         Qb / W queries and the embeddings are all-gathered first (two collectives per batch instead of one).
@@ -112,7 +116,23 @@ class RetrievalEngine:
         else:
             self.n_enc = self.n_srch = self.n_ctx
             self.enc_streams = self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_ctx)]
-        self.ctxs: List[_Ctx] = [self._make_ctx() for _ in range(self.n_ctx)]
+        # ENCODE GROUPS: one encoder forward serves G consecutive batches (their token blocks are slices of one [G * q_loc, seq]
+        # block, their searches stay per batch).  A forward over 4096 tokens leaves the MFMA GEMMs of a bge-class model with
+        # 48 - 144 tiles on 256 CUs; 8192 tokens cost 1.66 x, 16 384 tokens 2.78 x of the 4096-token forward (tools/bench_encoder.py).
+        # 'auto': two batches per forward when a batch is >= 2048 tokens of a hidden > 384 model, one otherwise; single rank only.
+        if encode_group == "auto":
+            encode_group = 2 if (self.encode and hidden > 384 and self.q_loc * self.seq >= 2048) else 1
+        self.enc_group = max(1, int(os.environ.get("CRS_ENCODE_GROUP", encode_group)))
+        if self.multi or self.gather_q or not self.encode:
+            self.enc_group = 1
+        while self.n_ctx % self.enc_group:
+            self.enc_group -= 1
+        self.groups: List[_Group] = []
+        self.ctxs: List[_Ctx] = []
+        for g0 in range(0, self.n_ctx, self.enc_group):
+            grp = self._make_group(list(range(g0, g0 + self.enc_group)))
+            self.groups.append(grp)
+            self.ctxs.extend(self._make_ctx(grp, j) for j in range(self.enc_group))
         # segments of a batch, in order; the lane each runs on; the collective that follows it (N > 1)
         self.segs = [self._seg_encode, self._seg_search] + ([self._seg_merge] if self.multi else [])
         self.seg_lanes = ["E", "S", "S"][: len(self.segs)]
@@ -124,17 +144,29 @@ class RetrievalEngine:
         self.collectives_per_batch = sum(1 for e in self.exchanges if e is not None)
         self._issued = 0
         self._warm = False
+        self._seg_events = None     # measure_search_segment_ms: (start, end) events of the search segments
 
     # ---- buffers ---------------------------------------------------------------------------------------------------
-    def _make_ctx(self) -> _Ctx:
+    def _make_group(self, members) -> _Group:
+        torch, v, dev = self.torch, self.view, self.dev
+        g = _Group()
+        n = len(members) * self.q_loc
+        g.members = members
+        g.ids = torch.zeros((n, self.seq), dtype=torch.int32, device=dev)
+        g.lens = torch.ones(n, dtype=torch.int32, device=dev)
+        g.q_out = torch.empty((n, v.dim), dtype=torch.float32, device=dev)
+        g.q16 = torch.empty((n, self.pd), dtype=torch.float16, device=dev)
+        g.enc_ws = (torch.empty(self.enc.workspace_bytes(n, self.seq), dtype=torch.uint8, device=dev) if self.encode else None)
+        g.ev_enc = torch.cuda.Event()
+        g.n_enc = 0
+        return g
+
+    def _make_ctx(self, grp: _Group, slot: int) -> _Ctx:
         torch, v, dev = self.torch, self.view, self.dev
         c = _Ctx()
-        c.ids = torch.zeros((self.q_loc, self.seq), dtype=torch.int32, device=dev)
-        c.lens = torch.ones(self.q_loc, dtype=torch.int32, device=dev)
-        c.q_out = torch.empty((self.q_loc, v.dim), dtype=torch.float32, device=dev)
-        c.q16 = torch.empty((self.q_loc, self.pd), dtype=torch.float16, device=dev)
-        c.enc_ws = (torch.empty(self.enc.workspace_bytes(self.q_loc, self.seq), dtype=torch.uint8, device=dev)
-                    if self.encode else None)
+        c.grp, c.slot, c.n_sub = grp, slot, 0
+        lo, hi = slot * self.q_loc, (slot + 1) * self.q_loc
+        c.ids, c.lens, c.q_out, c.q16 = grp.ids[lo:hi], grp.lens[lo:hi], grp.q_out[lo:hi], grp.q16[lo:hi]   # views of the group's blocks
         c.ws = torch.empty(nat.scan_workspace_bytes(self.nq_all, v.dim, self.k_scan, v.n), dtype=torch.uint8, device=dev)
         c.cand_s = torch.empty((self.nq_all, self.k_scan), dtype=torch.float32, device=dev)
         c.cand_i = torch.empty((self.nq_all, self.k_scan), dtype=torch.int64, device=dev)
@@ -149,7 +181,7 @@ class RetrievalEngine:
         if self.gather_q:
             c.q_all32 = torch.empty((self.nq_all, v.dim), dtype=torch.float32, device=dev)
             c.q_all16 = torch.empty((self.nq_all, self.pd), dtype=torch.float16, device=dev)
-        c.ev_enc, c.ev_done = torch.cuda.Event(), torch.cuda.Event()
+        c.ev_done = torch.cuda.Event()
         return c
 
     def set_tokens(self, ctx_index: int, ids, lens, stream=None) -> None:
@@ -164,12 +196,13 @@ class RetrievalEngine:
             c.ev_done.record(st)
 
     # ---- segments --------------------------------------------------------------------------------------------------
-    def _seg_encode(self, c: _Ctx) -> None:      # token ids -> fp32 embeddings + the scan's fp16 query block
+    def _seg_encode(self, c: _Ctx) -> None:      # token ids -> fp32 embeddings + the scan's fp16 query block (the whole group's)
+        g = c.grp
         if self.encode:
-            self.enc.forward(c.ids, c.lens, out=c.q_out, workspace=c.enc_ws, q16_out=c.q16, slab_type=self.view.slab_type,
+            self.enc.forward(g.ids, g.lens, out=g.q_out, workspace=g.enc_ws, q16_out=g.q16, slab_type=self.view.slab_type,
                              small_lds=self.small_lds)
         else:
-            nat.queries_to_f16(c.q_out, self.view.slab_type, out=c.q16)
+            nat.queries_to_f16(g.q_out, self.view.slab_type, out=g.q16)
 
     def _seg_search(self, c: _Ctx, refine: Optional[bool] = None) -> None:   # all queries x this rank's shard -> wire block
         v = self.view
@@ -200,25 +233,41 @@ class RetrievalEngine:
         """Issue one batch from buffer set ctx_index: encode on an encoder lane, search (+ exchange + merge) on a search lane.
         Returns the (scores, ids) DEVICE tensors the batch will fill (valid after ``wait(ctx_index)``)."""
         torch, c = self.torch, self.ctxs[ctx_index]
+        g = c.grp
         b = self._issued
         self._issued += 1
-        lane = {"E": self.enc_streams[b % self.n_enc], "S": self.srch_streams[b % self.n_srch]}
+        if c.slot == 0:
+            g.n_enc += 1
+        elif c.n_sub >= g.n_enc:
+            raise nat.NativeError("encode groups: submit the group's first buffer set before the others (step() / search_token_batches do)")
+        c.n_sub += 1
+        lane = {"E": self.enc_streams[((b - c.slot) // self.enc_group) % self.n_enc], "S": self.srch_streams[b % self.n_srch]}
         prev = None
         for j, seg in enumerate(self.segs):
+            if j == 0 and c.slot != 0:     # the group's forward was issued with its first buffer set
+                continue
             st = lane[self.seg_lanes[j]]
             with torch.cuda.stream(st):
                 if j == 0:
-                    st.wait_event(c.ev_done)          # the previous user of this buffer set is through (no-op before its first use)
+                    for m in g.members:    # the previous users of these buffer sets are through (no-op before their first use)
+                        st.wait_event(self.ctxs[m].ev_done)
                 elif st is not prev:
-                    st.wait_event(c.ev_enc)           # lane change: the encoder lane's output (and its collective) is complete
+                    st.wait_event(g.ev_enc)           # lane change: the encoder lane's output (and its collective) is complete
+                timed = j == 1 and self._seg_events is not None
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
                 if c.graphs is not None:
                     c.graphs[j].replay()
                 else:
                     seg(c)
+                if timed:
+                    e1.record(st)
+                    self._seg_events.append((e0, e1))
                 if self.exchanges[j] is not None:
                     self.exchanges[j](c)
                 if j == 0:
-                    c.ev_enc.record(st)
+                    g.ev_enc.record(st)
                 if j == len(self.segs) - 1:
                     c.ev_done.record(st)
             prev = st
@@ -237,21 +286,26 @@ class RetrievalEngine:
             return
         torch = self.torch
         torch.cuda.synchronize()
-        for i, c in enumerate(self.ctxs):
+        for g in self.groups:
             for _ in range(2):
-                self.submit(i)
+                for i in g.members:
+                    self.submit(i)
             torch.cuda.synchronize()
             if self.use_graph:
                 # thread_local: with N > 1 the process group's watchdog thread polls events while we capture
                 try:
-                    gl = []
-                    for j, seg in enumerate(self.segs):
-                        st = (self.enc_streams if self.seg_lanes[j] == "E" else self.srch_streams)[0]
-                        g_ = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
-                            seg(c)
-                        gl.append(g_)
-                    c.graphs = gl
+                    for i in g.members:
+                        c, gl = self.ctxs[i], []
+                        for j, seg in enumerate(self.segs):
+                            if j == 0 and c.slot != 0:      # one encode graph per group, held by its first buffer set
+                                gl.append(None)
+                                continue
+                            st = (self.enc_streams if self.seg_lanes[j] == "E" else self.srch_streams)[0]
+                            g_ = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
+                                seg(c)
+                            gl.append(g_)
+                        c.graphs = gl
                 except Exception as exc:   # noqa: BLE001 -- report and keep going without graphs
                     print(f"[engine] hipGraph capture failed on rank {self.rank} ({exc!r}); launching eagerly", file=sys.stderr, flush=True)
                     self.use_graph = False
@@ -275,23 +329,10 @@ class RetrievalEngine:
         torch.cuda.synchronize()
         evs = []
         for r in range(max(2, rounds)):
-            for c in self.ctxs:
-                b = self._issued
-                self._issued += 1
-                st_e, st_s = self.enc_streams[b % self.n_enc], self.srch_streams[b % self.n_srch]
-                with torch.cuda.stream(st_e):
-                    st_e.wait_event(c.ev_done)
-                    c.graphs[0].replay()
-                    c.ev_enc.record(st_e)
-                with torch.cuda.stream(st_s):
-                    st_s.wait_event(c.ev_enc)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(st_s)
-                    c.graphs[1].replay()
-                    e1.record(st_s)
-                    c.ev_done.record(st_s)
-                if r:
-                    evs.append((e0, e1))
+            self._seg_events = [] if r else None
+            self.step()
+            evs += self._seg_events or []
+        self._seg_events = None
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
 
@@ -316,7 +357,9 @@ class RetrievalEngine:
             m = pending.pop(i)
             return s[:m].cpu().numpy(), r[:m].cpu().numpy(), st[:m].cpu().numpy()
 
+        G = self.enc_group
         nb = 0
+        first = None          # tokens of the open group's first batch (fill for a group the input does not complete)
         for ids, lens in batches:
             i = nb % self.n_ctx
             if i in pending:
@@ -329,9 +372,26 @@ class RetrievalEngine:
                 ids = np.concatenate([ids, np.repeat(ids[:1], self.q_loc - m, axis=0)])
                 lens = np.concatenate([lens, np.repeat(lens[:1], self.q_loc - m)])
             self.set_tokens(i, ids, lens)
-            self.submit(i)
+            if i % G == 0:
+                first = (ids, lens)
             pending[i] = m
             order.append(i)
             nb += 1
+            if i % G == G - 1:            # the group's token block is complete: one forward, G searches
+                for j in range(i - G + 1, i + 1):
+                    self.submit(j)
+        tail = nb % G
+        if tail:                          # an incomplete last group: its free buffer sets repeat the group's first batch
+            i0 = (nb - tail) % self.n_ctx
+            fill = list(range(i0 + tail, i0 + G))
+            for j in fill:
+                if j in pending:
+                    order.remove(j)
+                    yield collect(j)
+                self.set_tokens(j, *first)
+            for j in range(i0, i0 + G):
+                self.submit(j)
+            for j in fill:
+                self.wait(j)
         for i in list(order):
             yield collect(i)

@@ -127,3 +127,37 @@ def test_dynamic_schedule_inside_a_graph(cuda):
             g.replay()
             torch.cuda.synchronize()
             assert np.array_equal(out_i.cpu().numpy(), si) and np.array_equal(out_s.cpu().numpy(), ss)
+
+
+@pytest.mark.parametrize("n,d,nq,k,pct,gran", [
+    (300_000, 768, 64, 16, 85, 8),     # C5's kernel (16-slot chain) with the default schedule
+    (300_001, 768, 17, 10, 100, 1),
+    (250_000, 384, 64, 32, 50, 4),     # padded to 512-element rows, 32-slot chain
+])
+def test_dynamic_schedule_int8(cuda, n, d, nq, k, pct, gran):
+    import torch
+    from rag import _native as nat
+    c = scan_ref.synth_corpus(n, d, seed=77 + k)
+    q_np = scan_ref.synth_queries(c, nq, seed=78).astype(np.float16)
+    c8, sc = scan_ref.quantize_rows_i8(c)
+    pd = nat.padded_dim(d, nat.SLAB_I8)
+    q = torch.zeros((nq, pd), dtype=torch.float16)
+    q[:, :d] = torch.from_numpy(q_np)
+    s = torch.zeros((n, pd), dtype=torch.int8)
+    s[:, :d] = torch.from_numpy(c8)
+    q, s, scales = q.to(cuda), s.to(cuda), torch.from_numpy(sc).to(cuda)
+
+    def search(poison):
+        ws = torch.full((nat.scan_workspace_bytes(nq, d, k, n),), poison, dtype=torch.uint8, device=q.device)
+        a, b = nat.cosine_topk(q, s, n, d, k, slab_type=nat.SLAB_I8, scales=scales, workspace=ws)
+        torch.cuda.synchronize()
+        return a.cpu().numpy(), b.cpu().numpy()
+
+    with _Env(CRS_TB_DYN=0):
+        ss, si = search(0xAB)
+    with _Env(CRS_TB_DYN=pct, CRS_TB_DYN_G=gran, CRS_TB_DYN_MIN=4):
+        ds, di = search(0xAB)
+        ds2, di2 = search(0xFF)
+    assert np.array_equal(si, di) and np.array_equal(ss, ds)
+    assert np.array_equal(di, di2) and np.array_equal(ds, ds2)
+    check_topk(ds, di, scan_ref.full_scores_f64(scan_ref.dequantized_queries(q_np), c8, sc), k)
