@@ -274,8 +274,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--scan-only", action="store_true", help="diagnostic: skip the encoder (NOT the metric)")
-    ap.add_argument("--streams", type=int, default=8,
-                    help="query batches in flight, one HIP stream each; a step is one batch on every stream")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="query batches (buffer sets) in flight; a step is one batch from every buffer set (0: the engine's rule, 8 or 24)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--enc-inflight", type=int, default=2,
                     help="enc-* workloads: forwards in flight, one stream each (a step = that many batches; 2 = what EmbeddingModel.embed does)")
@@ -396,7 +396,8 @@ def main():
     shape = ModelShape(ln_eps=1e-12, **arch)
     enc_w = synthetic_weights(shape, seed=7)
     enc = HipEncoder(shape, enc_w, device=dev)
-    n_ctx = max(1, args.streams)
+    # buffer sets in flight: the engine's rule (8; 24 for bge-class encoders, whose forwards serve 8 batches each) unless --streams says otherwise
+    n_ctx = args.streams if args.streams > 0 else RetrievalEngine.default_n_ctx(shape.hidden if not args.scan_only else 0)
     # Query set: R distinct queries (>= --recall-queries, a whole number of batches; the first n_ctx batches are the ones the
     # timed loop keeps in flight).  strong: every rank holds the SAME global batches; weak: per-rank queries.
     n_batches = max(n_ctx, -(-max(args.recall_queries, 1) // qb)) if strong else n_ctx

@@ -18,8 +18,12 @@ of a few microseconds each (latency, not work), a scan is one kernel that wants 
 kernel with > 48 KB of LDS cannot start on a CU that holds two scan workgroups.  ``lanes='split'`` gives the streams ROLES --
 encoder forwards of upcoming batches on encoder lanes, searches on a search lane, tied by events per buffer set -- and asks the
 encoder for its <= 48 KB kernel forms (``CRS_ENC_SMALL_LDS`` in the descriptor's flags: per call, not process-wide).
-``'batch'`` keeps every batch wholly on its own stream.  ``'auto'`` splits for MiniLM-class encoders (hidden <= 384) over scans
-of >= 512 MB per batch, where it measured faster, and keeps one lane per batch otherwise.
+``'batch'`` keeps every batch wholly on its own stream.  ``'auto'`` splits over scans of >= 512 MB per batch, where it measured
+faster (bge-class encoders: single rank only, together with encode groups), and keeps one lane per batch
+otherwise.
+
+Encode groups.  With role lanes a bge-class encoder forward serves G = 8 consecutive batches (``encode_group``): the per-batch
+searches are unchanged, the forward's GEMMs see 8 x the tokens (C3: 134 -> 165 k q/s).  See ``__init__``.
 """
 from __future__ import annotations
 
@@ -53,8 +57,13 @@ class _Group:
 
 
 class RetrievalEngine:
+    @staticmethod
+    def default_n_ctx(hidden: int) -> int:
+        """Buffer sets in flight: 8; 24 for bge-class encoders (three groups of 8 batches over two encoder lanes, see ENCODE GROUPS)."""
+        return 24 if hidden > 384 else 8
+
     def __init__(self, encoder, view: ShardView, queries_per_batch: int, seq: int, top_k: int, *, k_scan: int = 24, k_scan_exact: int = 0,
-                 refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 8, lanes: str = "auto",
+                 refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 0, lanes: str = "auto",
                  enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
                  queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True,
                  enc_small_lds="auto", enc_cus: int = 0, encode_group="auto"):
@@ -93,11 +102,11 @@ class RetrievalEngine:
         self.pd = nat.padded_dim(view.dim, view.slab_type)
         scan_bytes = view.n * self.pd * (1 if view.slab_type == nat.SLAB_I8 else 2)
         hidden = encoder.shape.hidden if encoder is not None else view.dim
-        self.pipelined = lanes == "split" or (lanes == "auto" and self.encode and hidden <= 384 and scan_bytes >= (512 << 20))
+        self.pipelined = lanes == "split" or (lanes == "auto" and self.encode and scan_bytes >= (512 << 20) and (hidden <= 384 or not self.multi))
         # <= 48 KB kernel forms of the encoder (they can start beside a scan's resident workgroups): with role lanes always;
         # 'auto' otherwise keeps the default forms
         self.small_lds = self.pipelined if enc_small_lds == "auto" else bool(enc_small_lds)
-        self.n_ctx = max(1, int(n_ctx))
+        self.n_ctx = int(n_ctx) if int(n_ctx) > 0 else self.default_n_ctx(hidden if (self.encode and self.pipelined and not self.multi) else 0)
         self.use_graph = bool(graphs)
         if self.pipelined:
             # two encoder lanes feed ONE search lane at every shard size (one encoder lane starves scans of <= 2.5 M rows); a
@@ -117,13 +126,16 @@ class RetrievalEngine:
             self.n_enc = self.n_srch = self.n_ctx
             self.enc_streams = self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_ctx)]
         # ENCODE GROUPS: one encoder forward serves G consecutive batches (their token blocks are slices of one [G * q_loc, seq]
-        # block, their searches stay per batch).  A forward over 4096 tokens leaves the MFMA GEMMs of a bge-class model with
-        # 48 - 144 tiles on 256 CUs; 8192 tokens cost 1.66 x, 16 384 tokens 2.78 x of the 4096-token forward (tools/bench_encoder.py).
-        # 'auto': two batches per forward when a batch is >= 2048 tokens of a hidden > 384 model, one otherwise; single rank only.
+        # block; the searches stay per batch).  A bge-class forward over one 256-query batch (4096 tokens) leaves its GEMMs with
+        # 48 - 144 tiles for 256 CUs: 1.70 ms per 256 queries alone, 1.41 at two batches per forward, 1.18 at four
+        # (tools/bench_encoder.py); beside the scans, C3 134 -> 165 k q/s and C5 34.4 -> 39.3 k with G = 8 over 24 buffer sets on role
+        # lanes (tools/r3_group.sh).  MiniLM-class forwards are launch-latency chains whatever their size: + 1 - 2 % on C4, - 10 % on
+        # C2, so they stay ungrouped.  The price is latency: a batch's search waits for its group's forward.
+        # 'auto': 8 batches per forward for hidden > 384 under role lanes, one otherwise; single rank only.
         if encode_group == "auto":
-            encode_group = 2 if (self.encode and hidden > 384 and self.q_loc * self.seq >= 2048) else 1
+            encode_group = 8 if (self.encode and self.pipelined and hidden > 384) else 1
         self.enc_group = max(1, int(os.environ.get("CRS_ENCODE_GROUP", encode_group)))
-        if self.multi or self.gather_q or not self.encode:
+        if self.multi or not self.encode:
             self.enc_group = 1
         while self.n_ctx % self.enc_group:
             self.enc_group -= 1
