@@ -396,8 +396,10 @@ def main():
     shape = ModelShape(ln_eps=1e-12, **arch)
     enc_w = synthetic_weights(shape, seed=7)
     enc = HipEncoder(shape, enc_w, device=dev)
-    # buffer sets in flight: the engine's rule (8; 24 for bge-class encoders, whose forwards serve 8 batches each) unless --streams says otherwise
-    n_ctx = args.streams if args.streams > 0 else RetrievalEngine.default_n_ctx(shape.hidden if not args.scan_only else 0)
+    # buffer sets in flight: the engine's rule (8; 16 / 24 with encode groups) unless --streams says otherwise
+    n_ctx = RetrievalEngine.plan_layout(shape.hidden, rows * pd * (1 if slab_type == nat.SLAB_I8 else 2), encode=not args.scan_only, multi=multi,
+                                        lanes=args.lanes, encode_group=args.encode_group if args.encode_group > 0 else "auto",
+                                        n_ctx=args.streams, enc_lanes=args.enc_lanes, search_lanes=args.search_lanes)["n_ctx"]
     # Query set: R distinct queries (>= --recall-queries, a whole number of batches; the first n_ctx batches are the ones the
     # timed loop keeps in flight).  strong: every rank holds the SAME global batches; weak: per-rank queries.
     n_batches = max(n_ctx, -(-max(args.recall_queries, 1) // qb)) if strong else n_ctx

@@ -58,9 +58,33 @@ class _Group:
 
 class RetrievalEngine:
     @staticmethod
-    def default_n_ctx(hidden: int) -> int:
-        """Buffer sets in flight: 8; 24 for bge-class encoders (three groups of 8 batches over two encoder lanes, see ENCODE GROUPS)."""
-        return 24 if hidden > 384 else 8
+    def plan_layout(hidden: int, scan_bytes: int, *, encode: bool = True, multi: bool = False, lanes: str = "auto", encode_group="auto",
+                    n_ctx: int = 0, enc_lanes: int = 0, search_lanes: int = 0) -> dict:
+        """Lanes, encode groups and buffer sets for an encoder of width `hidden` beside scans of `scan_bytes` per batch (measured
+        rules; every explicit argument wins over its rule):
+          * role lanes ('split') over scans of >= 512 MB, else every batch on its own stream;
+          * bge-class encoders (hidden > 384; single rank): 8 batches per encoder forward, 24 buffer sets, 2 encoder + 1 search lane;
+          * MiniLM-class over SHORT scans (< 2 GB: one rank's share of a 4- or 8-GPU C4 step): the 38-launch forward is what the
+            lanes wait for -- 8 batches per forward on ONE encoder lane, 16 buffer sets, and TWO search lanes so that a batch's tail
+            of small kernels and the next batch's sweep overlap (8-GPU rank proxy: 0.255 -> 0.203 ms per batch);
+          * MiniLM-class over long scans (C4 on one GPU): 2 encoder + 1 search lane, no groups (+ 1 - 2 % only, and a single
+            search lane keeps per-kernel durations in a trace meaningful)."""
+        pipelined = lanes == "split" or (lanes == "auto" and encode and scan_bytes >= (512 << 20) and (hidden <= 384 or not multi))
+        if encode_group == "auto":
+            big = hidden > 384
+            encode_group = 8 if (encode and pipelined and (big or scan_bytes < (2 << 30))) else 1
+        encode_group = max(1, int(os.environ.get("CRS_ENCODE_GROUP", encode_group))) if encode else 1
+        if n_ctx <= 0:
+            n_ctx = 8 if encode_group == 1 else (24 if hidden > 384 else 16)
+        while n_ctx % encode_group:
+            encode_group -= 1
+        if pipelined:
+            short_minilm = encode_group > 1 and hidden <= 384
+            n_enc = enc_lanes if enc_lanes > 0 else (1 if short_minilm else 2)
+            n_srch = search_lanes if search_lanes > 0 else (2 if short_minilm else 1)
+        else:
+            n_enc = n_srch = n_ctx
+        return {"pipelined": pipelined, "encode_group": encode_group, "n_ctx": n_ctx, "n_enc": n_enc, "n_srch": n_srch}
 
     def __init__(self, encoder, view: ShardView, queries_per_batch: int, seq: int, top_k: int, *, k_scan: int = 24, k_scan_exact: int = 0,
                  refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 0, lanes: str = "auto",
@@ -102,43 +126,32 @@ class RetrievalEngine:
         self.pd = nat.padded_dim(view.dim, view.slab_type)
         scan_bytes = view.n * self.pd * (1 if view.slab_type == nat.SLAB_I8 else 2)
         hidden = encoder.shape.hidden if encoder is not None else view.dim
-        self.pipelined = lanes == "split" or (lanes == "auto" and self.encode and scan_bytes >= (512 << 20) and (hidden <= 384 or not self.multi))
+        plan = self.plan_layout(hidden, scan_bytes, encode=self.encode, multi=self.multi, lanes=lanes, encode_group=encode_group,
+                                n_ctx=int(n_ctx), enc_lanes=enc_lanes, search_lanes=search_lanes)
+        self.pipelined, self.enc_group, self.n_ctx = plan["pipelined"], plan["encode_group"], plan["n_ctx"]
+        self.n_enc, self.n_srch = plan["n_enc"], plan["n_srch"]
         # <= 48 KB kernel forms of the encoder (they can start beside a scan's resident workgroups): with role lanes always;
         # 'auto' otherwise keeps the default forms
         self.small_lds = self.pipelined if enc_small_lds == "auto" else bool(enc_small_lds)
-        self.n_ctx = int(n_ctx) if int(n_ctx) > 0 else self.default_n_ctx(hidden if (self.encode and self.pipelined and not self.multi) else 0)
         self.use_graph = bool(graphs)
         if self.pipelined:
-            # two encoder lanes feed ONE search lane at every shard size (one encoder lane starves scans of <= 2.5 M rows); a
-            # second search lane would overlap consecutive scans (1 - 2 % on 10 M rows) and make per-kernel durations meaningless
-            self.n_enc = enc_lanes if enc_lanes > 0 else 2
-            self.n_srch = search_lanes if search_lanes > 0 else 1
             self.enc_cus = int(os.environ.get("CRS_ENC_CUS", enc_cus))
             if self.enc_cus > 0:
-                # encoder lanes confined to a few CUs each (lane i: CUs [i * enc_cus, (i + 1) * enc_cus)): the 38-launch chain is
-                # latency-bound and has a whole scan (two with two lanes) to finish in, so it does not need the chip -- and the
-                # sweep's dynamic tile schedule (scan_tb.hip) gives the workgroups on those CUs fewer tiles
+                # A/B: encoder lanes confined to a few CUs each (lane i: CUs [i * enc_cus, (i + 1) * enc_cus)); measured no gain
+                # (DESIGN.md section 4): what the encoder costs the sweep is its kernel boundaries, not the CUs it sits on
                 self.enc_streams = [nat.cu_masked_stream(i * self.enc_cus, self.enc_cus, self.dev) for i in range(self.n_enc)]
             else:
                 self.enc_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_enc)]
             self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_srch)]
         else:
-            self.n_enc = self.n_srch = self.n_ctx
             self.enc_streams = self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_ctx)]
         # ENCODE GROUPS: one encoder forward serves G consecutive batches (their token blocks are slices of one [G * q_loc, seq]
         # block; the searches stay per batch).  A bge-class forward over one 256-query batch (4096 tokens) leaves its GEMMs with
         # 48 - 144 tiles for 256 CUs: 1.70 ms per 256 queries alone, 1.41 at two batches per forward, 1.18 at four
         # (tools/bench_encoder.py); beside the scans, C3 134 -> 165 k q/s and C5 34.4 -> 39.3 k with G = 8 over 24 buffer sets on role
-        # lanes (tools/r3_group.sh).  MiniLM-class forwards are launch-latency chains whatever their size: + 1 - 2 % on C4, - 10 % on
-        # C2, so they stay ungrouped.  The price is latency: a batch's search waits for its group's forward.
-        # 'auto': 8 batches per forward for hidden > 384 under role lanes, one otherwise; single rank only.
-        if encode_group == "auto":
-            encode_group = 8 if (self.encode and self.pipelined and hidden > 384) else 1
-        self.enc_group = max(1, int(os.environ.get("CRS_ENCODE_GROUP", encode_group)))
-        if self.multi or not self.encode:
-            self.enc_group = 1
-        while self.n_ctx % self.enc_group:
-            self.enc_group -= 1
+        # lanes (tools/r3_group.sh).  A MiniLM-class forward is a launch-latency chain whatever its size: grouping takes it off
+        # the critical path of short scans (plan_layout), and is worth + 1 - 2 % on C4, - 10 % on C2.  The price is latency: a
+        # batch's search waits for its group's forward.  N > 1: the group's embeddings travel in ONE all-gather.
         self.groups: List[_Group] = []
         self.ctxs: List[_Ctx] = []
         for g0 in range(0, self.n_ctx, self.enc_group):
@@ -148,12 +161,16 @@ class RetrievalEngine:
         # segments of a batch, in order; the lane each runs on; the collective that follows it (N > 1)
         self.segs = [self._seg_encode, self._seg_search] + ([self._seg_merge] if self.multi else [])
         self.seg_lanes = ["E", "S", "S"][: len(self.segs)]
+        self.last_search_seg = 1
         self.exchanges = [None] * len(self.segs)
         if self.multi and self.gather_q:   # queries encoded in shards (or per-rank queries): embeddings gathered first
-            self.exchanges[0] = lambda c: dist.all_gather_into_tensor(c.q_all32, c.q_out)
+            self.exchanges[0] = lambda c: dist.all_gather_into_tensor(c.grp.q_gath, c.grp.q_out)
         if self.multi:                     # THE exchange of a sharded search: every rank's wire block
-            self.exchanges[1] = lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)
-        self.collectives_per_batch = sum(1 for e in self.exchanges if e is not None)
+            self.exchanges[self.last_search_seg] = lambda c: dist.all_gather_into_tensor(c.wire.gathered, c.wire.buf)
+        # (the embeddings of a group travel in one all-gather: 1 / G of a collective per batch)
+        self.collectives_per_batch = round(sum((1.0 / self.enc_group if j == 0 else 1.0) for j, e in enumerate(self.exchanges) if e is not None), 4)
+        if self.collectives_per_batch == int(self.collectives_per_batch):
+            self.collectives_per_batch = int(self.collectives_per_batch)
         self._issued = 0
         self._warm = False
         self._seg_events = None     # measure_search_segment_ms: (start, end) events of the search segments
@@ -169,6 +186,8 @@ class RetrievalEngine:
         g.q_out = torch.empty((n, v.dim), dtype=torch.float32, device=dev)
         g.q16 = torch.empty((n, self.pd), dtype=torch.float16, device=dev)
         g.enc_ws = (torch.empty(self.enc.workspace_bytes(n, self.seq), dtype=torch.uint8, device=dev) if self.encode else None)
+        # N > 1 with gathered queries: every rank's block of the group in ONE all-gather, [world, G * q_loc, dim]
+        g.q_gath = torch.empty((self.world * n, v.dim), dtype=torch.float32, device=dev) if (self.multi and self.gather_q) else None
         g.ev_enc = torch.cuda.Event()
         g.n_enc = 0
         return g
@@ -191,9 +210,11 @@ class RetrievalEngine:
             c.fin_s = torch.empty((self.nq_all, self.k), dtype=torch.float32, device=dev)
             c.fin_i = torch.empty((self.nq_all, self.k), dtype=torch.int64, device=dev)
         if self.gather_q:
-            c.q_all32 = torch.empty((self.nq_all, v.dim), dtype=torch.float32, device=dev)
+            # (one batch per forward: the all-gather's output IS the batch's query block)
+            c.q_all32 = grp.q_gath if (grp.q_gath is not None and len(grp.members) == 1) else torch.empty((self.nq_all, v.dim), dtype=torch.float32, device=dev)
             c.q_all16 = torch.empty((self.nq_all, self.pd), dtype=torch.float16, device=dev)
         c.ev_done = torch.cuda.Event()
+        c.ev_seg = [torch.cuda.Event() for _ in range(4)]     # a segment's output is complete (next segment on another lane)
         return c
 
     def set_tokens(self, ctx_index: int, ids, lens, stream=None) -> None:
@@ -216,26 +237,39 @@ class RetrievalEngine:
         else:
             nat.queries_to_f16(g.q_out, self.view.slab_type, out=g.q16)
 
-    def _seg_search(self, c: _Ctx, refine: Optional[bool] = None) -> None:   # all queries x this rank's shard -> wire block
+    def _seg_search(self, c: _Ctx) -> None:   # all queries x this rank's shard -> wire block
+        self._seg_scan(c)
+        if self.refine:
+            self._seg_post(c)
+
+    def _seg_scan(self, c: _Ctx) -> None:     # the sweep: k' candidates per query (no re-rank configured: the final lists)
         v = self.view
-        refine = self.refine if refine is None else refine
         qa32 = c.q_all32 if self.gather_q else c.q_out
         if self.gather_q:
             if not self.multi:     # proxy: the local queries tiled in place of the all-gather
                 c.q_all32.view(self.shard_w, self.q_loc, v.dim).copy_(c.q_out.unsqueeze(0).expand(self.shard_w, self.q_loc, v.dim))
+            elif self.enc_group > 1:   # this batch's rows of every rank's block of the group: global query r * q_loc + i, as ungrouped
+                c.q_all32.view(self.world, self.q_loc, v.dim).copy_(
+                    c.grp.q_gath.view(self.world, self.enc_group, self.q_loc, v.dim)[:, c.slot])
             nat.queries_to_f16(qa32, v.slab_type, out=c.q_all16)
         qa16 = c.q_all16 if self.gather_q else c.q16
-        if refine:
+        if self.refine:
             nat.cosine_topk(qa16, v.slab, v.n, v.dim, self.k_scan, slab_type=v.slab_type, scales=v.scales, id_base=v.id_base,
                             workspace=c.ws, out_scores=c.cand_s, out_ids=c.cand_i)
+        else:
+            nat.cosine_topk(qa16, v.slab, v.n, v.dim, self.k, slab_type=v.slab_type, scales=v.scales, id_base=v.id_base,
+                            workspace=c.ws, out_scores=c.wire.scores, out_ids=c.wire.ids)
+
+    def _seg_post(self, c: _Ctx) -> None:     # fp32 re-rank + certificate + escalation -> this rank's wire block
+        v = self.view
+        qa32 = c.q_all32 if self.gather_q else c.q_out
+        qa16 = c.q_all16 if self.gather_q else c.q16
+        if self.refine:
             nat.refine_f32_cert(qa32, qa16, v.shadow, v.n, v.id_base, c.cand_i, c.cand_s, self.k, v.row_err_max, v.slab_type,
                                 c.exact_ws, self.exact_cap, out_scores=c.wire.scores, out_ids=c.wire.ids, status=c.status)
             if self.exact:
                 nat.escalate_exact(qa32, qa16, v.slab, v.shadow, v.n, v.id_base, self.k, c.wire.scores, c.wire.ids, c.status,
                                    c.exact_ws, self.exact_cap, scales=v.scales)
-        else:
-            nat.cosine_topk(qa16, v.slab, v.n, v.dim, self.k, slab_type=v.slab_type, scales=v.scales, id_base=v.id_base,
-                            workspace=c.ws, out_scores=c.wire.scores, out_ids=c.wire.ids)
 
     def _seg_merge(self, c: _Ctx) -> None:       # N > 1: the gathered wire blocks -> global top-k
         nat.merge_topk_wire(c.wire.gathered, self.world, self.nq_all, self.k, self.k, out_scores=c.fin_s, out_ids=c.fin_i)
@@ -254,9 +288,11 @@ class RetrievalEngine:
             raise nat.NativeError("encode groups: submit the group's first buffer set before the others (step() / search_token_batches do)")
         c.n_sub += 1
         lane = {"E": self.enc_streams[((b - c.slot) // self.enc_group) % self.n_enc], "S": self.srch_streams[b % self.n_srch]}
-        prev = None
+        prev, prev_ev = None, None
+        n_seg = len(self.segs)
         for j, seg in enumerate(self.segs):
             if j == 0 and c.slot != 0:     # the group's forward was issued with its first buffer set
+                prev_ev = g.ev_enc
                 continue
             st = lane[self.seg_lanes[j]]
             with torch.cuda.stream(st):
@@ -264,23 +300,28 @@ class RetrievalEngine:
                     for m in g.members:    # the previous users of these buffer sets are through (no-op before their first use)
                         st.wait_event(self.ctxs[m].ev_done)
                 elif st is not prev:
-                    st.wait_event(g.ev_enc)           # lane change: the encoder lane's output (and its collective) is complete
-                timed = j == 1 and self._seg_events is not None
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(st)
+                    st.wait_event(prev_ev)            # lane change: the previous segment's output (and its collective) is complete
+                timed = self._seg_events is not None
+                if timed and j == 1:
+                    c.t0 = torch.cuda.Event(enable_timing=True)
+                    c.t0.record(st)
                 if c.graphs is not None:
                     c.graphs[j].replay()
                 else:
                     seg(c)
-                if timed:
+                if timed and j == self.last_search_seg:
+                    e1 = torch.cuda.Event(enable_timing=True)
                     e1.record(st)
-                    self._seg_events.append((e0, e1))
+                    self._seg_events.append((c.t0, e1))
                 if self.exchanges[j] is not None:
                     self.exchanges[j](c)
                 if j == 0:
                     g.ev_enc.record(st)
-                if j == len(self.segs) - 1:
+                    prev_ev = g.ev_enc
+                elif j + 1 < n_seg and lane[self.seg_lanes[j + 1]] is not st:
+                    c.ev_seg[j].record(st)
+                    prev_ev = c.ev_seg[j]
+                if j == n_seg - 1:
                     c.ev_done.record(st)
             prev = st
         return (c.fin_s, c.fin_i) if self.multi else (c.wire.scores, c.wire.ids)
@@ -349,7 +390,9 @@ class RetrievalEngine:
         return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
 
     def describe_lanes(self) -> str:
-        return (f"{self.n_enc} encoder + {self.n_srch} search (encoder kernels <= 48 KB of LDS)" if self.pipelined else "one per batch")
+        if not self.pipelined:
+            return "one per batch"
+        return f"{self.n_enc} encoder + {self.n_srch} search (encoder kernels <= 48 KB of LDS)"
 
     # ---- the product entry: many query batches through the pipeline -------------------------------------------------
     def search_token_batches(self, batches):

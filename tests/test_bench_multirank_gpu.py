@@ -30,11 +30,13 @@ def _run(extra, port):
 
 def test_two_rank_strong_step_is_exact_vs_fp32(cuda):
     d = _run(["--workload", "c4", "--rows", "600000", "--encode", "sharded", "--lanes", "split"], 29533)   # (auto: from 4 GPUs on / 512 MB scans)
-    assert d["config"]["lanes"].startswith("2 encoder + 1 search")
     c = d["config"]
+    # short scans under role lanes: ONE encoder lane whose forward serves a group of batches (3 buffer sets: a group of 3),
+    # two search lanes; the group's embeddings travel in one all-gather
+    assert c["lanes"].startswith("1 encoder + 2 search") and c["batches_per_encoder_forward"] == 3
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert c["corpus_rows"] == 600_000 and c["rows_per_gpu"] == 300_000 and c["queries_per_batch"] == 64
-    assert c["queries_per_step"] == 64 * 3 and c["collectives_per_batch"] == 2
+    assert c["queries_per_step"] == 64 * 3 and c["collectives_per_batch"] == pytest.approx(1 + 1 / 3, abs=1e-3)
     assert c["query_encode"].startswith("sharded: 32 of 64")            # each rank encodes half of the global batch
     assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
     assert c["recall_at_10_vs_fp32"]["max_abs_score_err_vs_fp64"] < 1e-5
@@ -83,8 +85,18 @@ def _run_single_rccl(extra):
 def test_single_rank_rccl_strong_step(cuda):
     d = _run_single_rccl(["--workload", "c4", "--rows", "1400000"])                      # 1.07 GB scan: auto picks the split lanes
     c = d["config"]
-    assert c["lanes"].startswith("2 encoder + 1 search")
+    assert c["lanes"].startswith("1 encoder + 2 search") and c["batches_per_encoder_forward"] == 3   # a short scan: grouped forwards, two search lanes
     assert c["dist_single_rank"] is True and c["collectives_per_batch"] == 1 and c["hip_graph"] is True
+    assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
+
+
+def test_single_rank_rccl_grouped_query_gather(cuda):
+    """Encode groups with gathered queries over RCCL: the group's embeddings in ONE all-gather (issued on the encoder lane), each
+    batch's rows picked out of it, the wire-block all-gathers issued from the two search lanes."""
+    d = _run_single_rccl(["--workload", "c4", "--rows", "1400000", "--scaling", "weak"])
+    c = d["config"]
+    assert c["lanes"].startswith("1 encoder + 2 search") and c["batches_per_encoder_forward"] == 3
+    assert c["collectives_per_batch"] == pytest.approx(1 + 1 / 3, abs=1e-3)
     assert c["check_ok"] and c["recall_at_10_vs_fp32"]["timed_path"] == 1.0
 
 
