@@ -280,6 +280,143 @@ __global__ __launch_bounds__(NW * 64) void attention_seq_kernel(const _Float16* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the whole-sequence kernel on v_mfma_f32_16x16x32_f16 with QT query tiles per wave (index build, head_dim 32 / 64).
+// The kernel above reads an 8-byte K or V^T fragment from LDS for EVERY 16x16x16 MFMA and uses it for one 16-query tile:
+// 16 flops per LDS byte, i.e. the LDS port bounds it at half the matrix pipe's rate before any latency shows (measured:
+// 170 TFLOP/s on bge-base's 512-token sequences, 21 % of the index build).  Here
+//   * a wave owns QT = 2 query tiles (32 queries): a fragment is read once (ds_read_b128, 16 bytes per lane) and feeds
+//     QT MFMAs of twice the depth -- 4 x fewer LDS instructions per flop;
+//   * S^T = K Q^T contracts 32 head-dim elements per MFMA (K rows in natural order: lane = key row, 8 elements of the step);
+//   * O^T += V^T P^T contracts 32 KEYS per MFMA.  P^T leaves the score accumulators as 4 consecutive keys of a 16-key tile
+//     per lane; two tiles (2 s, 2 s + 1) side by side ARE a lane's 8 k-values of the 32-key step if k is numbered
+//     (lane group g, tile, i) instead of key order -- any order works as long as V^T uses the same one, so V^T is STAGED
+//     with its keys permuted inside every 32-key group: position = 8 (key % 16 / 4) + 4 (key / 16 % 2) + key % 4.
+//     No shuffle, no LDS round trip for P;
+//   * row pitches HD + 8 and SMAX + 8 halves: 16-byte aligned rows whose 16 lanes land on 16 distinct 4-bank groups.
+// Same masking, scaling and online softmax (softmax_step, per query tile); accumulation ORDER differs from the kernel above
+// (32-deep products), so results agree to fp32 rounding, not bit for bit.
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+
+template <int HD, int SMAX, int NW, int QT>
+__global__ __launch_bounds__(NW * 64) void attention_seq32_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ lens,
+                                                                 _Float16* __restrict__ ctx, int seq, int hidden) {
+  constexpr int KS = HD / 32, NT = HD / 16;
+  constexpr int KROW = HD + 8, VROW = SMAX + 8;
+  constexpr int kThr = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) char attn_smem[];
+  _Float16* sK = reinterpret_cast<_Float16*>(attn_smem);                       // [SMAX][KROW]
+  _Float16* sVt = sK + SMAX * KROW;                                            // [HD][VROW], keys permuted per 32-key group
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int heads = hidden / HD;
+  int unit = blockIdx.x;
+  if ((gridDim.x & 15) == 0) unit = (((unit >> 4) << 3) + (unit & 7)) * 2 + ((unit >> 3) & 1);   // neighbouring heads on one XCD (see above)
+  const int b = unit / heads, h = unit % heads;
+  const int len = min(max(lens[b], 1), seq);
+  const size_t row_stride = (size_t)3 * hidden;
+  const _Float16* base = qkv + (size_t)b * seq * row_stride + h * HD;
+  const float scale = 1.44269504088896341f / sqrtf((float)HD);
+  const int kend = (len + KB - 1) / KB * KB;
+
+  constexpr int CH = HD / 8;
+  for (int id = tid; id < kend * CH; id += kThr) {
+    const int key = id / CH, c = id % CH;
+    f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (key < seq) kv = *reinterpret_cast<const f16x8*>(base + (size_t)key * row_stride + c * 8 + hidden);
+    *reinterpret_cast<f16x8*>(&sK[key * KROW + c * 8]) = kv;
+  }
+  for (int id = tid; id < (kend / 4) * CH; id += kThr) {
+    const int kg = id / CH, c = id % CH;        // keys 4 kg .. 4 kg + 3, head-dim elements 8 c .. 8 c + 7
+    f16x8 vv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kr = kg * 4 + j;
+      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      vv[j] = (kr < seq) ? *reinterpret_cast<const f16x8*>(base + (size_t)kr * row_stride + c * 8 + 2 * hidden) : z;
+    }
+    const int k0 = kg * 4, kk = k0 & 31;
+    const int pos = (k0 & ~31) + ((kk & 15) >> 2) * 8 + (kk >> 4) * 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      *reinterpret_cast<f16x4*>(&sVt[(c * 8 + e) * VROW + pos]) = f16x4{vv[0][e], vv[1][e], vv[2][e], vv[3][e]};
+  }
+  __syncthreads();
+
+  for (int q0 = wave * (16 * QT); q0 < seq; q0 += NW * 16 * QT) {
+    f16x8 qf[QT][KS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int qr = q0 + t * 16 + lr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[t][ks] = (qr < seq) ? *reinterpret_cast<const f16x8*>(base + (size_t)qr * row_stride + ks * 32 + g * 8) : z;
+      }
+    }
+    f32x4 o[QT][NT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      m_run[t] = -1e30f;
+      l_run[t] = 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) o[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kb = 0; kb < len; kb += KB) {
+      f32x4 sc[QT][4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const f16x8 kf = *reinterpret_cast<const f16x8*>(&sK[(kb + ct * 16 + lr) * KROW + ks * 32 + g * 8]);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) sc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], sc[t][ct], 0, 0, 0);
+        }
+      }
+      f16x8 pb[QT][2];      // P^T as B operands of the two 32-key steps: (tile 2 s, tile 2 s + 1) side by side
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        float alpha;
+        f16x4 pf[4];
+        softmax_step(sc[t], kb + 4 * g, len, scale, m_run[t], l_run[t], alpha, pf);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          pb[t][s2] = f16x8{pf[2 * s2][0], pf[2 * s2][1], pf[2 * s2][2], pf[2 * s2][3],
+                            pf[2 * s2 + 1][0], pf[2 * s2 + 1][1], pf[2 * s2 + 1][2], pf[2 * s2 + 1][3]};
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[t][n][i] *= alpha;
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(&sVt[(n * 16 + lr) * VROW + kb + s2 * 32 + g * 8]);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[t][s2], o[t][n], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int qr = q0 + t * 16 + lr;
+      if (qr < seq) {
+        const float inv = 1.0f / l_run[t];
+        _Float16* dst = ctx + ((size_t)b * seq + qr) * hidden + h * HD;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const f16x4 v = {(_Float16)(o[t][n][0] * inv), (_Float16)(o[t][n][1] * inv), (_Float16)(o[t][n][2] * inv), (_Float16)(o[t][n][3] * inv)};
+          *reinterpret_cast<f16x4*>(dst + n * 16 + 4 * g) = v;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,
@@ -296,6 +433,15 @@ int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int ba
       hipLaunchKernelGGL(kernel, g2, dim3(threads), lds, stream, qkv, lens, ctx, seq, hidden);
       return (int)hipGetLastError();
     };
+    static int x32 = -1;   // CRS_ATTN_X32=0: the 16x16x16 whole-sequence kernel (A/B runs)
+    if (x32 < 0) { const char* e = getenv("CRS_ATTN_X32"); x32 = (e && e[0] == '0') ? 0 : 1; }
+    static int qt4 = -1;   // CRS_ATTN_QT=4: four query tiles per wave (A/B)
+    if (qt4 < 0) { const char* e = getenv("CRS_ATTN_QT"); qt4 = (e && e[0] == '4') ? 1 : 0; }
+    if (x32 && qt4 && hd == 32 && seq <= 256) return launch(&attention_seq32_kernel<32, 256, 4, 4>, 256, (256 * 40 + 32 * 264) * 2);
+    if (x32 && qt4 && hd == 64 && seq <= 512 && seq > 256) return launch(&attention_seq32_kernel<64, 512, 8, 4>, 512, (512 * 72 + 64 * 520) * 2);
+    if (x32 && hd == 32 && seq <= 256) return launch(&attention_seq32_kernel<32, 256, 4, 2>, 256, (256 * 40 + 32 * 264) * 2);
+    if (x32 && hd == 64 && seq <= 512 && seq > 256) return launch(&attention_seq32_kernel<64, 512, 8, 2>, 512, (512 * 72 + 64 * 520) * 2);
+    if (x32 && hd == 64 && seq <= 256) return launch(&attention_seq32_kernel<64, 256, 4, 2>, 256, (256 * 72 + 64 * 264) * 2);
     if (hd == 32 && seq <= 256) return launch(&attention_seq_kernel<32, 256, 4>, 256, (256 * 36 + 32 * 260) * 2);
     if (hd == 16 && seq <= 256) return launch(&attention_seq_kernel<16, 256, 4>, 256, (256 * 20 + 16 * 260) * 2);
     if (hd == 64 && seq <= 512 && seq > 256) return launch(&attention_seq_kernel<64, 512, 8>, 512, (512 * 68 + 64 * 516) * 2);

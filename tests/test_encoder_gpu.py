@@ -116,7 +116,10 @@ def test_padding_is_ignored(cuda):
     wide = np.zeros((4, 70), dtype=np.int32)
     wide[:, :20] = ids
     b = enc.forward(wide, lens).cpu().numpy()
-    assert np.abs(a - b).max() < 2e-5
+    # 20 tokens run the blocked attention kernel (16-deep MFMA products), 70 the whole-sequence one (32-deep products, round 3): the
+    # scores agree to fp32 rounding, the fp16 probabilities then differ in a last bit here and there -- 5e-5 on unit embeddings
+    # (measured; exactly 0 while both kernels shared one accumulation order), a quarter of the 2e-4 parity bar against the oracle
+    assert np.abs(a - b).max() < 1e-4
 
 
 @pytest.mark.parametrize("cfg,slab", [(er.MINILM_L6, 0), (er.BGE_BASE, 1), (er.TINY, 0)])

@@ -28,6 +28,12 @@ done
 for w in enc-minilm enc-bge; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 3 > $O/${TAG}_stats_$w.log 2>&1 || { tail -5 $O/${TAG}_stats_$w.log; exit 1; }
 done
+# per-queue timelines of the same traces (which lane waits for what): C4 (2 encoder + 1 search lanes), C3 / C5 (encode groups), and
+# the dynamic tile schedule's own check (identical lists, the counter's value, time per setting)
+mkdir -p $O/${TAG}_profiles
+for w in c4 c3 c5; do python3 tools/timeline.py $O/${TAG}_stats_$w 2 > $O/${TAG}_profiles/${TAG}_timeline_$w.txt 2>&1 || true; done
+python3 tools/tb_dyn_check.py 10000000 > $O/${TAG}_profiles/${TAG}_tb_dyn_check.txt 2>&1 || true
+bash tools/r3_multi.sh > $O/${TAG}_profiles/${TAG}_layouts.txt 2>&1 || true
 echo "stats done"
 # PMC passes: counters only with --kernel-trace (one --pmc set per run)
 for c in FETCH_SIZE WRITE_SIZE; do
