@@ -223,7 +223,7 @@ def bench_pipeline(args, torch, nat, dev):
             p.vector_store.create_index(chunks, emb)
         torch.cuda.synchronize()
         t_index = time.perf_counter() - t_index
-        n_q = qb * max(1, args.streams)
+        n_q = qb * (args.streams if args.streams > 0 else 8)     # queries per retrieve_batch call: eight engine batches
         queries = [" ".join(rng.choice(words, size=int(rng.integers(5, 12)))) for _ in range(n_q)]
         for _ in range(max(1, args.warmup)):
             p.retrieve_batch(queries)
