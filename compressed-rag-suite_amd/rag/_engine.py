@@ -59,7 +59,7 @@ class _Group:
 class RetrievalEngine:
     @staticmethod
     def plan_layout(hidden: int, scan_bytes: int, *, encode: bool = True, multi: bool = False, lanes: str = "auto", encode_group="auto",
-                    n_ctx: int = 0, enc_lanes: int = 0, search_lanes: int = 0) -> dict:
+                    n_ctx: int = 0, enc_lanes: int = 0, search_lanes: int = 0, group_cap: int = 0) -> dict:
         """Lanes, encode groups and buffer sets for an encoder of width `hidden` beside scans of `scan_bytes` per batch (measured
         rules; every explicit argument wins over its rule):
           * role lanes ('split') over scans of >= 512 MB, else every batch on its own stream;
@@ -67,21 +67,26 @@ class RetrievalEngine:
           * MiniLM-class over SHORT scans (< 2 GB: one rank's share of a 4- or 8-GPU C4 step): the 38-launch forward is what the
             lanes wait for -- 8 batches per forward on ONE encoder lane, 16 buffer sets, and TWO search lanes so that a batch's tail
             of small kernels and the next batch's sweep overlap (8-GPU rank proxy: 0.255 -> 0.203 ms per batch);
-          * MiniLM-class over long scans (C4 on one GPU): 2 encoder + 1 search lane, no groups (+ 1 - 2 % only, and a single
-            search lane keeps per-kernel durations in a trace meaningful)."""
+          * MiniLM-class over long scans (C4 on one GPU): 16 batches per forward on one encoder lane, 32 buffer sets, ONE search lane
+            -- 38 kernel boundaries per 16 batches instead of per batch: 47.3 -> 48.6 - 49.0 k q/s on one box (8 per forward over 16
+            sets: 48.6 k; a second search lane: 49.8 k, not taken -- consecutive scans then overlap and a trace's per-kernel
+            durations stop meaning "one scan").
+        group_cap > 0 limits the group (a caller that knows its calls bring fewer batches than a group holds)."""
         pipelined = lanes == "split" or (lanes == "auto" and encode and scan_bytes >= (512 << 20) and (hidden <= 384 or not multi))
+        big, short = hidden > 384, scan_bytes < (2 << 30)
         if encode_group == "auto":
-            big = hidden > 384
-            encode_group = 8 if (encode and pipelined and (big or scan_bytes < (2 << 30))) else 1
+            encode_group = (8 if (big or short) else 16) if (encode and pipelined) else 1
         encode_group = max(1, int(os.environ.get("CRS_ENCODE_GROUP", encode_group))) if encode else 1
+        if group_cap > 0:
+            encode_group = min(encode_group, group_cap)
         if n_ctx <= 0:
-            n_ctx = 8 if encode_group == 1 else (24 if hidden > 384 else 16)
+            n_ctx = 8 if encode_group == 1 else (3 * encode_group if big else 2 * encode_group)
         while n_ctx % encode_group:
             encode_group -= 1
         if pipelined:
-            short_minilm = encode_group > 1 and hidden <= 384
-            n_enc = enc_lanes if enc_lanes > 0 else (1 if short_minilm else 2)
-            n_srch = search_lanes if search_lanes > 0 else (2 if short_minilm else 1)
+            minilm_groups = encode_group > 1 and not big
+            n_enc = enc_lanes if enc_lanes > 0 else (1 if minilm_groups else 2)
+            n_srch = search_lanes if search_lanes > 0 else (2 if (minilm_groups and short) else 1)
         else:
             n_enc = n_srch = n_ctx
         return {"pipelined": pipelined, "encode_group": encode_group, "n_ctx": n_ctx, "n_enc": n_enc, "n_srch": n_srch}
@@ -90,7 +95,7 @@ class RetrievalEngine:
                  refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 0, lanes: str = "auto",
                  enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
                  queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True,
-                 enc_small_lds="auto", enc_cus: int = 0, encode_group="auto"):
+                 enc_small_lds="auto", enc_cus: int = 0, encode_group="auto", group_cap: int = 0):
         """queries_per_batch: the GLOBAL batch every rank searches (strong scaling), or with ``queries_per_rank`` the queries
         THIS rank contributes (weak scaling: the scan then sees world x that many).  encode_shard = W > 1: each rank encodes
         Qb / W queries and the embeddings are all-gathered first (two collectives per batch instead of one).
@@ -127,7 +132,7 @@ class RetrievalEngine:
         scan_bytes = view.n * self.pd * (1 if view.slab_type == nat.SLAB_I8 else 2)
         hidden = encoder.shape.hidden if encoder is not None else view.dim
         plan = self.plan_layout(hidden, scan_bytes, encode=self.encode, multi=self.multi, lanes=lanes, encode_group=encode_group,
-                                n_ctx=int(n_ctx), enc_lanes=enc_lanes, search_lanes=search_lanes)
+                                n_ctx=int(n_ctx), enc_lanes=enc_lanes, search_lanes=search_lanes, group_cap=int(group_cap))
         self.pipelined, self.enc_group, self.n_ctx = plan["pipelined"], plan["encode_group"], plan["n_ctx"]
         self.n_enc, self.n_srch = plan["n_enc"], plan["n_srch"]
         # <= 48 KB kernel forms of the encoder (they can start beside a scan's resident workgroups): with role lanes always;
@@ -415,7 +420,6 @@ class RetrievalEngine:
 
         G = self.enc_group
         nb = 0
-        first = None          # tokens of the open group's first batch (fill for a group the input does not complete)
         for ids, lens in batches:
             i = nb % self.n_ctx
             if i in pending:
@@ -428,8 +432,6 @@ class RetrievalEngine:
                 ids = np.concatenate([ids, np.repeat(ids[:1], self.q_loc - m, axis=0)])
                 lens = np.concatenate([lens, np.repeat(lens[:1], self.q_loc - m)])
             self.set_tokens(i, ids, lens)
-            if i % G == 0:
-                first = (ids, lens)
             pending[i] = m
             order.append(i)
             nb += 1
@@ -437,17 +439,9 @@ class RetrievalEngine:
                 for j in range(i - G + 1, i + 1):
                     self.submit(j)
         tail = nb % G
-        if tail:                          # an incomplete last group: its free buffer sets repeat the group's first batch
-            i0 = (nb - tail) % self.n_ctx
-            fill = list(range(i0 + tail, i0 + G))
-            for j in fill:
-                if j in pending:
-                    order.remove(j)
-                    yield collect(j)
-                self.set_tokens(j, *first)
-            for j in range(i0, i0 + G):
+        if tail:                          # an incomplete last group: its forward runs over the whole token block (the free slices
+            i0 = (nb - tail) % self.n_ctx  # hold earlier, valid tokens), only the real batches are searched
+            for j in range(i0, i0 + tail):
                 self.submit(j)
-            for j in fill:
-                self.wait(j)
         for i in list(order):
             yield collect(i)

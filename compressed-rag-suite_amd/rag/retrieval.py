@@ -122,7 +122,7 @@ class ContextRetriever:
             raise
 
     # ---- batched retrieval (additive; the reference has no batched entry point) --------------------------------------
-    def _engine_for(self, fetch: int, seq: int):
+    def _engine_for(self, fetch: int, seq: int, n_batches: int = 0):
         """The throughput engine (rag/_engine.py: role lanes, hipGraph replay, several batches in flight) for this store /
         encoder pair, or None when the store's layout needs the general path (several shards, filters, top_k > 64)."""
         store, model = self.vector_store, self.embedding_model
@@ -130,11 +130,14 @@ class ContextRetriever:
         enc = getattr(model, "model", None)
         if view is None or enc is None or fetch > 64 or not getattr(model, "normalize", True):
             return None
-        key = (fetch, seq, view.n, int(view.slab.data_ptr()), self.batch_queries)
+        # one encoder forward serves a group of batches (rag/_engine.py): never more of them than a call of this size brings
+        cap = 1 << (max(1, n_batches).bit_length() - 1)
+        key = (fetch, seq, view.n, int(view.slab.data_ptr()), self.batch_queries, min(cap, 16))
         if self._engine_key != key:
             from rag._engine import RetrievalEngine
             self._engine = RetrievalEngine(enc, view, self.batch_queries, seq, fetch, k_scan=store.refine_overfetch,
-                                           refine=view.shadow is not None, exact=store.refine_exact, exact_cap=store.exact_cap)
+                                           refine=view.shadow is not None, exact=store.refine_exact, exact_cap=store.exact_cap,
+                                           group_cap=cap)
             self._engine_key = key
         return self._engine
 
@@ -148,7 +151,7 @@ class ContextRetriever:
             token_ids = model.tokenize(list(queries))
             longest = max(len(t) for t in token_ids)
             seq = next((st for st in (16, 32, 64) if longest <= st and st <= model.shape.max_seq), None)
-            eng = self._engine_for(min(fetch, store.collection.count()), seq) if seq else None
+            eng = self._engine_for(min(fetch, store.collection.count()), seq, -(-len(queries) // qb)) if seq else None
         if eng is None:                       # general path: one encoder pass + one search launch for the whole list
             emb = model.embed_device(list(queries)) if hasattr(model, "embed_device") else model.embed(list(queries))
             if not hasattr(store, "search_rows"):          # any store with the additive search_batch (duck-typed)

@@ -4,5 +4,6 @@ show() { grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read())
 for w in c4 c3 c5 c2; do
 timeout -k 10 400 python3 bench.py --workload $w --no-cpu-baseline --recall-queries 2048 2>gpurun_out/r3_def_err.log | show "$w defaults" || tail -5 gpurun_out/r3_def_err.log
 done
-timeout -k 10 400 python3 bench.py --workload c3 --through-pipeline --steps 5 2>gpurun_out/r3_def_err.log | grep '^{' | cut -c1-300 || tail -5 gpurun_out/r3_def_err.log
+timeout -k 10 300 python3 bench.py --rows 1250000 --proxy-encode-shard 8 --no-cpu-baseline --recall-queries 512 2>gpurun_out/r3_def_err.log | show "proxy8" || tail -5 gpurun_out/r3_def_err.log
+for w in c2 c4; do timeout -k 10 400 python3 bench.py --workload $w --through-pipeline --steps 5 2>gpurun_out/r3_def_err.log | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('   pipeline $w', [(r['queries_per_call'], r['queries_per_s']) for r in d['config']['results']])" || tail -5 gpurun_out/r3_def_err.log; done
 python3 -m pytest tests -m gpu -x -q > gpurun_out/r3_gpu_tests.log 2>&1; tail -3 gpurun_out/r3_gpu_tests.log
