@@ -165,9 +165,14 @@ class RetrievalEngine:
             self.groups.append(grp)
             self.ctxs.extend(self._make_ctx(grp, j) for j in range(self.enc_group))
         # segments of a batch, in order; the lane each runs on; the collective that follows it (N > 1)
-        self.segs = [self._seg_encode, self._seg_search] + ([self._seg_merge] if self.multi else [])
-        self.seg_lanes = ["E", "S", "S"][: len(self.segs)]
-        self.last_search_seg = 1
+        # gathered queries (sharded / per-rank encode, or its one-rank proxy): a second per-GROUP segment on the encoder lane,
+        # behind the all-gather, lays the group's queries out batch by batch and writes their fp16 blocks -- two kernels per group
+        # instead of two per batch in front of every scan
+        self.segs = ([self._seg_encode] + ([self._seg_prep] if self.gather_q else []) + [self._seg_search] +
+                     ([self._seg_merge] if self.multi else []))
+        self.group_segs = 2 if self.gather_q else 1          # leading segments that run once per group (first buffer set)
+        self.seg_lanes = ["E"] * self.group_segs + ["S", "S"][: len(self.segs) - self.group_segs]
+        self.last_search_seg = self.group_segs
         self.exchanges = [None] * len(self.segs)
         if self.multi and self.gather_q:   # queries encoded in shards (or per-rank queries): embeddings gathered first
             self.exchanges[0] = lambda c: dist.all_gather_into_tensor(c.grp.q_gath, c.grp.q_out)
@@ -194,6 +199,11 @@ class RetrievalEngine:
         g.enc_ws = (torch.empty(self.enc.workspace_bytes(n, self.seq), dtype=torch.uint8, device=dev) if self.encode else None)
         # N > 1 with gathered queries: every rank's block of the group in ONE all-gather, [world, G * q_loc, dim]
         g.q_gath = torch.empty((self.world * n, v.dim), dtype=torch.float32, device=dev) if (self.multi and self.gather_q) else None
+        if self.gather_q:      # the group's queries batch by batch: [G, nq_all, dim] fp32 and the scans' fp16 blocks
+            G = len(members)
+            g.q_all32 = (g.q_gath if (g.q_gath is not None and G == 1) else       # (one batch per forward: the all-gather's output IS it)
+                         torch.empty((G * self.nq_all, v.dim), dtype=torch.float32, device=dev))
+            g.q_all16 = torch.empty((G * self.nq_all, self.pd), dtype=torch.float16, device=dev)
         g.ev_enc = torch.cuda.Event()
         g.n_enc = 0
         return g
@@ -216,9 +226,8 @@ class RetrievalEngine:
             c.fin_s = torch.empty((self.nq_all, self.k), dtype=torch.float32, device=dev)
             c.fin_i = torch.empty((self.nq_all, self.k), dtype=torch.int64, device=dev)
         if self.gather_q:
-            # (one batch per forward: the all-gather's output IS the batch's query block)
-            c.q_all32 = grp.q_gath if (grp.q_gath is not None and len(grp.members) == 1) else torch.empty((self.nq_all, v.dim), dtype=torch.float32, device=dev)
-            c.q_all16 = torch.empty((self.nq_all, self.pd), dtype=torch.float16, device=dev)
+            c.q_all32 = grp.q_all32[slot * self.nq_all:(slot + 1) * self.nq_all]
+            c.q_all16 = grp.q_all16[slot * self.nq_all:(slot + 1) * self.nq_all]
         c.ev_done = torch.cuda.Event()
         c.ev_seg = [torch.cuda.Event() for _ in range(4)]     # a segment's output is complete (next segment on another lane)
         return c
@@ -243,6 +252,15 @@ class RetrievalEngine:
         else:
             nat.queries_to_f16(g.q_out, self.view.slab_type, out=g.q16)
 
+    def _seg_prep(self, c: _Ctx) -> None:     # gathered queries of the group -> per-batch fp32 blocks + fp16 scan blocks
+        g, v = c.grp, self.view
+        G = len(g.members)
+        if not self.multi:         # proxy: the local queries tiled in place of the all-gather
+            g.q_all32.view(G, self.shard_w, self.q_loc, v.dim).copy_(g.q_out.view(G, 1, self.q_loc, v.dim).expand(G, self.shard_w, self.q_loc, v.dim))
+        elif G > 1:                # batch j = rows j of every rank's block: global query r * q_loc + i, as ungrouped
+            g.q_all32.view(G, self.world, self.q_loc, v.dim).copy_(g.q_gath.view(self.world, G, self.q_loc, v.dim).transpose(0, 1))
+        nat.queries_to_f16(g.q_all32, v.slab_type, out=g.q_all16)
+
     def _seg_search(self, c: _Ctx) -> None:   # all queries x this rank's shard -> wire block
         self._seg_scan(c)
         if self.refine:
@@ -250,14 +268,6 @@ class RetrievalEngine:
 
     def _seg_scan(self, c: _Ctx) -> None:     # the sweep: k' candidates per query (no re-rank configured: the final lists)
         v = self.view
-        qa32 = c.q_all32 if self.gather_q else c.q_out
-        if self.gather_q:
-            if not self.multi:     # proxy: the local queries tiled in place of the all-gather
-                c.q_all32.view(self.shard_w, self.q_loc, v.dim).copy_(c.q_out.unsqueeze(0).expand(self.shard_w, self.q_loc, v.dim))
-            elif self.enc_group > 1:   # this batch's rows of every rank's block of the group: global query r * q_loc + i, as ungrouped
-                c.q_all32.view(self.world, self.q_loc, v.dim).copy_(
-                    c.grp.q_gath.view(self.world, self.enc_group, self.q_loc, v.dim)[:, c.slot])
-            nat.queries_to_f16(qa32, v.slab_type, out=c.q_all16)
         qa16 = c.q_all16 if self.gather_q else c.q16
         if self.refine:
             nat.cosine_topk(qa16, v.slab, v.n, v.dim, self.k_scan, slab_type=v.slab_type, scales=v.scales, id_base=v.id_base,
@@ -297,7 +307,7 @@ class RetrievalEngine:
         prev, prev_ev = None, None
         n_seg = len(self.segs)
         for j, seg in enumerate(self.segs):
-            if j == 0 and c.slot != 0:     # the group's forward was issued with its first buffer set
+            if j < self.group_segs and c.slot != 0:     # the group's forward (+ query layout) was issued with its first buffer set
                 prev_ev = g.ev_enc
                 continue
             st = lane[self.seg_lanes[j]]
@@ -308,7 +318,7 @@ class RetrievalEngine:
                 elif st is not prev:
                     st.wait_event(prev_ev)            # lane change: the previous segment's output (and its collective) is complete
                 timed = self._seg_events is not None
-                if timed and j == 1:
+                if timed and j == self.last_search_seg:
                     c.t0 = torch.cuda.Event(enable_timing=True)
                     c.t0.record(st)
                 if c.graphs is not None:
@@ -321,7 +331,7 @@ class RetrievalEngine:
                     self._seg_events.append((c.t0, e1))
                 if self.exchanges[j] is not None:
                     self.exchanges[j](c)
-                if j == 0:
+                if j == self.group_segs - 1:
                     g.ev_enc.record(st)
                     prev_ev = g.ev_enc
                 elif j + 1 < n_seg and lane[self.seg_lanes[j + 1]] is not st:
@@ -356,7 +366,7 @@ class RetrievalEngine:
                     for i in g.members:
                         c, gl = self.ctxs[i], []
                         for j, seg in enumerate(self.segs):
-                            if j == 0 and c.slot != 0:      # one encode graph per group, held by its first buffer set
+                            if j < self.group_segs and c.slot != 0:      # one encode (+ layout) graph per group, held by its first buffer set
                                 gl.append(None)
                                 continue
                             st = (self.enc_streams if self.seg_lanes[j] == "E" else self.srch_streams)[0]
