@@ -147,7 +147,7 @@ class RetrievalEngine:
                 self.enc_streams = [nat.cu_masked_stream(i * self.enc_cus, self.enc_cus, self.dev) for i in range(self.n_enc)]
             else:
                 self.enc_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_enc)]
-            # (search lanes as high-priority streams: measured null on C3 / C4 / C5 / the 8-GPU rank proxy, tools/r3_prio.sh)
+            # (search lanes, or the encoder lanes, as high-priority streams: measured null on C3 / C4 / C5 / the 8-GPU rank proxy, tools/r3_prio.sh)
             self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_srch)]
         else:
             self.enc_streams = self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_ctx)]
