@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kP8Threads, 2) void gemm8_kernel(const _Float16* __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int ncb = N / PN;
+  const int ncb = (N + PN - 1) / PN;     // N a multiple of 128: the last column block may be half a tile (round 3)
   const int n_tiles = ncb * (M / PM);
   const int G = (int)gridDim.x;
   // item order: column blocks of a row block are neighbours, and each XCD (hardware id % 8) walks one contiguous range of
@@ -98,11 +98,14 @@ __global__ __launch_bounds__(kP8Threads, 2) void gemm8_kernel(const _Float16* __
     bs.p[0] = uniform_ptr(A + (size_t)bs.m0 * K + kb);
     bs.p[1] = uniform_ptr(A + (size_t)(bs.m0 + 128) * K + kb);
     bs.p[2] = uniform_ptr(W + (size_t)bs.n0 * K + kb);
-    bs.p[3] = uniform_ptr(W + (size_t)(bs.n0 + 128) * K + kb);
+    // (half a column block: W rows n0 + 128 .. do not exist -- the second half tile re-reads the first; the waves that would
+    // multiply it skip their MFMAs and stores)
+    bs.p[3] = (bs.n0 + 128 < N) ? uniform_ptr(W + (size_t)(bs.n0 + 128) * K + kb) : bs.p[2];
     return bs;
   };
   int item = me;
   Bases cur = bases_of(item < n_items ? item : 0), nxt = cur;
+  bool wv = cur.n0 + wn * 64 < N;      // this wave's 64 output columns exist (wave-uniform)
   bool has_next = PERSIST && (item + G < n_items);
   if (has_next) nxt = bases_of(item + G);
   // k-tile kt of the current item (kt < nk) or k-tile kt - nk of the next one
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(kP8Threads, 2) void gemm8_kernel(const _Float16* __
 
 #define CRS_MFMA_QUAD(RT0, CT0)                                                                                         \
   if (VAR != 2) __builtin_amdgcn_s_setprio(1);                                                                          \
+  if (wv)                                                                                                               \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                      \
   _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                      \
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(kP8Threads, 2) void gemm8_kernel(const _Float16* __
   // stores, 128 bytes contiguous per row.  No workgroup barrier: the staging tiles are wave-private.
   const int c = lane & 15, q = lane >> 4;
   auto epilogue = [&](const Bases& bs) {
+    if (!wv) return;          // (its accumulators were never touched: still zero)
     f32x4 bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(kP8Threads, 2) void gemm8_kernel(const _Float16* __
     if (!has_next) break;
     item += G;
     cur = nxt;
+    wv = cur.n0 + wn * 64 < N;
     has_next = item + G < n_items;
     if (has_next) nxt = bases_of(item + G);
   }
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(kP8Threads, 2) void gemm8_kernel(const _Float16* __
 template <int MODE, int VAR>
 int launch8v(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k,
              int splits, int cus, hipStream_t stream) {
-  const int items = (n / PN) * (m / PM) * (MODE == 3 ? splits : 1);
+  const int items = ((n + PN - 1) / PN) * (m / PM) * (MODE == 3 ? splits : 1);
   // the stream pays for the fp16 epilogues (bias / GELU; + 8 % at K = 768 and 384: their VALU and stores sit beside the next item's
   // first phases) and measured 4 % slower for the fp32 + residual ones (the residual loads of the 16-row passes drain behind the
   // transfers in flight): those keep one workgroup per item.  CRS_GEMM8_VAR=1: one workgroup per item everywhere (A/B)
@@ -319,10 +325,14 @@ int launch8(const _Float16* a, const _Float16* w, const float* bias, const float
 bool gemm8_applies(int m, int n, int k, int mode) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("CRS_GEMM8"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!on || m % PM || n % PN || k % 128 || k < 256) return false;
+  // (N: whole 256-column blocks, or -- round 3, CRS_GEMM8_HALF=0 off -- a last block of 128: MiniLM's 384 / 1152)
+  static int half = -1;
+  if (half < 0) { const char* e = getenv("CRS_GEMM8_HALF"); half = (e && e[0] == '0') ? 0 : 1; }
+  const bool n_ok = n % PN == 0 || (half && n % 128 == 0 && n > PN);
+  if (!on || m % PM || !n_ok || k % 128 || k < 256) return false;
   static long min_wgs = -1;
   if (min_wgs < 0) { const char* e = getenv("CRS_GEMM8_MIN_WGS"); min_wgs = e ? atol(e) : 128; }
-  return (long)(m / PM) * (n / PN) >= min_wgs;
+  return (long)(m / PM) * ((n + PN - 1) / PN) >= min_wgs;
 }
 
 int gemm8_launch(const _Float16* a, const _Float16* w, const float* bias, const float* residual, void* out, int m, int n, int k, int mode,

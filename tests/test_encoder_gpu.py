@@ -34,7 +34,9 @@ def _cos(a, b):
                                    (4100, 1152, 384), (2049, 200, 128), (8192, 1536, 384), (3000, 384, 512), (5000, 96, 256),
                                    (4100, 2304, 768), (2049, 520, 768), (600, 3072, 768),
                                    # whole 256 x 256 tiles, >= 128 of them: the phase-scheduled kernel (enc_gemm8.hip), shortest and long K
-                                   (8192, 1024, 768), (4096, 2304, 256), (4096, 2048, 3072)])
+                                   (8192, 1024, 768), (4096, 2304, 256), (4096, 2048, 3072),
+                                   # ... with HALF a last column block (N = 128 mod 256, round 3): MiniLM's 384 and 1152, a 640
+                                   (16384, 384, 1536), (8192, 1152, 384), (16384, 640, 256)])
 def test_gemm_vs_torch_fp32(cuda, mode, m, n, k):
     import torch
     from rag._encoder import gemm_f16
