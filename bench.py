@@ -299,6 +299,8 @@ def main():
                     help="the encoder's <= 48 KB-of-LDS kernel forms (auto: with role lanes only)")
     ap.add_argument("--encode-group", type=int, default=0,
                     help="query batches served by ONE encoder forward (0: the engine's rule -- 2 for >= 2048-token batches of a bge-class model, else 1)")
+    ap.add_argument("--search-fuse", type=int, default=0,
+                    help="search segments replayed as ONE hipGraph (0: the engine's rule -- 4 inside an encode group on one rank, else 1)")
     ap.add_argument("--k-scan", type=int, default=0,
                     help="candidates the scan over-fetches for the fp32 re-rank (0: the library's rule, rag/_native.py overfetch: 24 on fp16 shards of >= 4 M rows, else 16)")
     ap.add_argument("--exact", default="auto", choices=("auto", "on", "off"),
@@ -437,7 +439,8 @@ def main():
                                encode_shard=(world if (strong and multi and want_shard) else 1),
                                proxy_encode_shard=args.proxy_encode_shard, encode=not args.scan_only,
                                enc_small_lds={"auto": "auto", "on": True, "off": False}[args.enc_small_lds],
-                               encode_group=args.encode_group if args.encode_group > 0 else "auto")
+                               encode_group=args.encode_group if args.encode_group > 0 else "auto",
+                               search_fuse=args.search_fuse if args.search_fuse > 0 else "auto")
 
     exact_mode = {"auto": "auto", "on": True, "off": False}[args.exact]
     eng = make_engine(refine, exact_mode)
@@ -681,7 +684,7 @@ def main():
             "config": {"workload": args.workload, "corpus_rows": corpus_rows, "rows_per_gpu": rows, "dim": dim,
                        "queries_per_batch": nq_all, "batches_per_step": n_ctx, "queries_per_step": q_per_step,
                        "distinct_queries_in_flight": q_per_step,
-                       "ms_per_batch": round(ms_step / n_ctx, 5), "lanes": eng.describe_lanes(), "batches_per_encoder_forward": eng.enc_group, "top_k": k, "k_scan": k_scan,
+                       "ms_per_batch": round(ms_step / n_ctx, 5), "lanes": eng.describe_lanes(), "batches_per_encoder_forward": eng.enc_group, "searches_per_graph": eng.search_fuse, "top_k": k, "k_scan": k_scan,
                        "slab": slab_kind, "refine_fp32": refine, "exact_escalation": bool(eng.exact), "encoder_in_step": not args.scan_only,
                        "engine": "rag._engine.RetrievalEngine (the object ContextRetriever.retrieve_batch drives)",
                        "encoder": ("all-MiniLM-L6-v2" if enc_name == "minilm" else "bge-base-en-v1.5") + " shape, seeded random weights",

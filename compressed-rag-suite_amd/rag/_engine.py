@@ -95,7 +95,7 @@ class RetrievalEngine:
                  refine: bool = True, exact="auto", exact_cap: int = nat.EXACT_CAP, n_ctx: int = 0, lanes: str = "auto",
                  enc_lanes: int = 0, search_lanes: int = 0, graphs: bool = True, dist=None, world: int = 1, rank: int = 0,
                  queries_per_rank: bool = False, encode_shard: int = 1, proxy_encode_shard: int = 1, encode: bool = True,
-                 enc_small_lds="auto", enc_cus: int = 0, encode_group="auto", group_cap: int = 0):
+                 enc_small_lds="auto", enc_cus: int = 0, encode_group="auto", group_cap: int = 0, search_fuse="auto"):
         """queries_per_batch: the GLOBAL batch every rank searches (strong scaling), or with ``queries_per_rank`` the queries
         THIS rank contributes (weak scaling: the scan then sees world x that many).  encode_shard = W > 1: each rank encodes
         Qb / W queries and the embeddings are all-gathered first (two collectives per batch instead of one).
@@ -158,6 +158,14 @@ class RetrievalEngine:
         # lanes (tools/r3_group.sh).  A MiniLM-class forward is a launch-latency chain whatever its size: grouping takes it off
         # the critical path of short scans (plan_layout), and is worth + 1 - 2 % on C4, - 10 % on C2.  The price is latency: a
         # batch's search waits for its group's forward.  N > 1: the group's embeddings travel in ONE all-gather.
+        # FUSED SEARCH GRAPHS (single rank): the search segments of F consecutive members of a group replayed as ONE hipGraph --
+        # a graph boundary on the search lane costs ~20 us (tools/timeline.py), 1.5 % of a C4 batch, once per F batches instead of
+        # once per batch.  The members' results then complete together.  N > 1 keeps one graph per batch: a collective follows each.
+        if search_fuse == "auto":
+            search_fuse = 4 if (not self.multi and self.enc_group % 4 == 0 and self.use_graph) else 1
+        self.search_fuse = max(1, int(os.environ.get("CRS_SEARCH_FUSE", search_fuse)))
+        if self.multi or self.enc_group % self.search_fuse:
+            self.search_fuse = 1
         self.groups: List[_Group] = []
         self.ctxs: List[_Ctx] = []
         for g0 in range(0, self.n_ctx, self.enc_group):
@@ -222,6 +230,7 @@ class RetrievalEngine:
         c.exact_ws = (torch.empty(nat.exact_workspace_bytes(self.nq_all, self.exact_cap), dtype=torch.uint8, device=dev)
                       if self.refine else None)
         c.graphs = None
+        c.chunk_graph = None
         if self.multi:
             c.fin_s = torch.empty((self.nq_all, self.k), dtype=torch.float32, device=dev)
             c.fin_i = torch.empty((self.nq_all, self.k), dtype=torch.int64, device=dev)
@@ -375,6 +384,14 @@ class RetrievalEngine:
                                 seg(c)
                             gl.append(g_)
                         c.graphs = gl
+                    if self.search_fuse > 1:
+                        j = self.last_search_seg
+                        for i0 in range(g.members[0], g.members[-1] + 1, self.search_fuse):
+                            g_ = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g_, stream=self.srch_streams[0], capture_error_mode="thread_local"):
+                                for i in range(i0, i0 + self.search_fuse):
+                                    self.segs[j](self.ctxs[i])
+                            self.ctxs[i0].chunk_graph = g_
                 except Exception as exc:   # noqa: BLE001 -- report and keep going without graphs
                     print(f"[engine] hipGraph capture failed on rank {self.rank} ({exc!r}); launching eagerly", file=sys.stderr, flush=True)
                     self.use_graph = False
@@ -383,8 +400,45 @@ class RetrievalEngine:
                     torch.cuda.synchronize()   # (no break: every rank must still run the same warm-up collectives)
         self._warm = True
 
-    def step(self) -> None:
+    def submit_chunk(self, i0: int) -> None:
+        """Buffer sets i0 .. i0 + search_fuse - 1 (i0 a multiple of search_fuse, their tokens in place) as one unit: the group's
+        forward if i0 opens its group, then ONE graph with the chunk's searches."""
+        torch, F = self.torch, self.search_fuse
+        c0 = self.ctxs[i0]
+        if F == 1 or c0.graphs is None or getattr(c0, "chunk_graph", None) is None:
+            for i in range(i0, i0 + F):
+                self.submit(i)
+            return
+        g = c0.grp
+        b = self._issued
+        self._issued += F
+        if c0.slot == 0:
+            g.n_enc += 1
+            st = self.enc_streams[(b // self.enc_group) % self.n_enc]
+            with torch.cuda.stream(st):
+                for m in g.members:
+                    st.wait_event(self.ctxs[m].ev_done)
+                for j in range(self.group_segs):
+                    c0.graphs[j].replay()
+                    if self.exchanges[j] is not None:
+                        self.exchanges[j](c0)
+                g.ev_enc.record(st)
+        elif c0.n_sub >= g.n_enc:
+            raise nat.NativeError("encode groups: submit the group's first buffer set before the others (step() / search_token_batches do)")
+        st = self.srch_streams[(b // F) % self.n_srch]
+        with torch.cuda.stream(st):
+            st.wait_event(g.ev_enc)
+            c0.chunk_graph.replay()
+            for i in range(i0, i0 + F):
+                self.ctxs[i].n_sub += 1
+                self.ctxs[i].ev_done.record(st)
+
+    def step(self, fused: bool = True) -> None:
         """One batch from every buffer set (the unit bench.py times)."""
+        if fused and self.search_fuse > 1:
+            for i0 in range(0, self.n_ctx, self.search_fuse):
+                self.submit_chunk(i0)
+            return
         for i in range(self.n_ctx):
             self.submit(i)
 
@@ -399,7 +453,7 @@ class RetrievalEngine:
         evs = []
         for r in range(max(2, rounds)):
             self._seg_events = [] if r else None
-            self.step()
+            self.step(fused=False)
             evs += self._seg_events or []
         self._seg_events = None
         torch.cuda.synchronize()
@@ -446,8 +500,8 @@ class RetrievalEngine:
             order.append(i)
             nb += 1
             if i % G == G - 1:            # the group's token block is complete: one forward, G searches
-                for j in range(i - G + 1, i + 1):
-                    self.submit(j)
+                for j in range(i - G + 1, i + 1, self.search_fuse):
+                    self.submit_chunk(j)
         tail = nb % G
         if tail:                          # an incomplete last group: its forward runs over the whole token block (the free slices
             i0 = (nb - tail) % self.n_ctx  # hold earlier, valid tokens), only the real batches are searched
