@@ -6,6 +6,7 @@
 1. Scratch.  Compiles each translation unit for gfx950 with -Rpass-analysis=kernel-resource-usage and fails when a kernel
    uses scratch memory (register spills) unless it is on the ALLOW list below -- the list names the cold instantiations that
    are known to spill, with the reason; every kernel a BASELINE configuration or a default plan selects must be clean.
+3. Tickets (scan_tb.hip / scan_i8.hip): the asm global_atomic_add's destination register is untouched until the vmcnt(0) behind it.
 2. Counted waits.  scan_w2_kernel (csrc/scan_w1.hip), gemm_big_kernel and gemm8_kernel pace their LDS reads / LDS-DMA with
    hand-counted s_waitcnt lgkmcnt(N) / vmcnt(N).  Those counts are only right while the compiler puts no SMEM load, scratch
    access or buffer instruction of its own between the counted statements: the device assembly of these kernels must have
@@ -31,6 +32,10 @@ ALLOW = [
     (r"scan_i8_kernel<768, 32, 32, -1>", "int8 threshold kernel: k > 48 on long streams only"),
 ]
 COUNTED = {"scan_w1.hip": ["scan_w2_kernel"], "enc_gemm_big.hip": ["gemm_big_kernel"], "enc_gemm8.hip": ["gemm8_kernel"]}
+# 3. Tickets.  scan_tb_kernel / scan_i8_kernel draw their dynamic tiles with an asm global_atomic_add whose returned value is first
+#    read behind a later s_waitcnt vmcnt(0) (the compiler does not count the asm's memory operation): between the atomic and that
+#    wait no instruction may touch the destination register (a copy or spill there would carry garbage).
+TICKETS = {"scan_tb.hip": "scan_tb_kernel", "scan_i8.hip": "scan_i8_kernel"}
 
 
 def demangle(names):
@@ -62,6 +67,21 @@ def analyse(path):
             for m in re.finditer(r"\.name:\s+(\S*(?:%s)\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)" % "|".join(COUNTED[base]), s):
                 if int(m.group(2)):
                     asm_bad.append((m.group(1), ["private_segment_fixed_size %s" % m.group(2)]))
+    if base in TICKETS:
+        s = subprocess.run([HIPCC, *FLAGS, "-S", path, "-o", "-"], capture_output=True, text=True).stdout
+        for m in re.finditer(r"^(_Z\S*%s\S*):\n(.*?)s_endpgm" % TICKETS[base], s, flags=re.S | re.M):
+            lines = m.group(2).splitlines()
+            for i, ln in enumerate(lines):
+                am = re.match(r"\s*global_atomic_add\s+(v\d+),", ln)
+                if not am:
+                    continue
+                reg = am.group(1)
+                for nxt in lines[i + 1:]:
+                    if re.match(r"\s*s_waitcnt\s+vmcnt\(0\)", nxt):
+                        break
+                    if re.search(r"\b%s\b" % reg, nxt) and not nxt.lstrip().startswith(";"):
+                        asm_bad.append((m.group(1), ["ticket register %s touched before its wait: %s" % (reg, nxt.strip())]))
+                        break
     return path, rows, asm_bad
 
 
