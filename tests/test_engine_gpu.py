@@ -89,3 +89,23 @@ def test_group_members_need_their_groups_first_buffer_set(world):
     eng.submit(0)
     eng.submit(1)
     eng.wait(1)
+
+
+def test_cu_masked_stream_runs_the_same_search(world):
+    """crs_stream_create_cu_masked (include/crs_hip.h): a stream confined to 32 CUs runs the library's kernels with the same
+    results (the encoder-placement A/B of DESIGN section 4 used it for the encoder lanes); a range past the device is refused."""
+    import torch
+    from rag import _native as nat
+    enc, view = world
+    st = nat.cu_masked_stream(0, 32, view.slab.device)
+    g = torch.Generator(device=view.slab.device).manual_seed(5)
+    q = torch.randn((8, DIM), device=view.slab.device, generator=g)
+    q16 = nat.queries_to_f16(q / q.norm(dim=1, keepdim=True))
+    s0, i0 = nat.cosine_topk(q16, view.slab, view.n, view.dim, K)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        s1, i1 = nat.cosine_topk(q16, view.slab, view.n, view.dim, K)
+    st.synchronize()
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    with pytest.raises(nat.NativeError):
+        nat.cu_masked_stream(250, 64, view.slab.device)
