@@ -240,7 +240,7 @@ def bench_pipeline(args, torch, nat, dev):
         # host / device split of one call: tokenisation, engine (device + readback), post-processing incl. the MMR encoder pass
         r = p.retriever
         t0 = time.perf_counter(); toks = p.embedding_model.tokenize(queries); t_tok = time.perf_counter() - t0
-        t0 = time.perf_counter(); hits = r._search_many(queries, k * 2 if r.rerank else k); t_search = time.perf_counter() - t0
+        t0 = time.perf_counter(); hits = [h for piece in r._search_many(queries, k * 2 if r.rerank else k) for h in piece]; t_search = time.perf_counter() - t0
         med = sorted(lat)[len(lat) // 2]
         results.append({"retrieval_config": label, "queries_per_call": n_q, "queries_per_batch": qb, "corpus_rows": rows,
                         "queries_per_s": round(n_q / med, 1), "ms_per_call_median": round(med * 1e3, 3),

@@ -142,7 +142,10 @@ class ContextRetriever:
         return self._engine
 
     def _search_many(self, queries: List[str], fetch: int):
-        """-> per query (scores fp32 [<= fetch], sidecar rows int64 [<= fetch]) numpy arrays, best first."""
+        """Generator over PIECES of the query list, in order: each piece a list of per-query (scores fp32 [<= fetch], sidecar rows
+        int64 [<= fetch]) numpy arrays, best first (or, once, a duck-typed store's search_batch dict).  With the throughput
+        engine a piece is one device batch, yielded as soon as it is through -- the caller builds that batch's dicts while the
+        device works on the following ones."""
         import numpy as _np
         model, store = self.embedding_model, self.vector_store
         qb = self.batch_queries
@@ -155,9 +158,11 @@ class ContextRetriever:
         if eng is None:                       # general path: one encoder pass + one search launch for the whole list
             emb = model.embed_device(list(queries)) if hasattr(model, "embed_device") else model.embed(list(queries))
             if not hasattr(store, "search_rows"):          # any store with the additive search_batch (duck-typed)
-                return store.search_batch(emb, top_k=fetch)
+                yield store.search_batch(emb, top_k=fetch)
+                return
             scores, rows = store.search_rows(emb, fetch)
-            return [(scores[i], rows[i]) for i in range(len(queries))]
+            yield [(scores[i], rows[i]) for i in range(len(queries))]
+            return
         pad = getattr(model.tokenizer, "pad_id", 0)
 
         def batches():
@@ -169,15 +174,14 @@ class ContextRetriever:
                     lens[r] = len(t)
                 yield ids, lens
 
-        out, tally = [], {"queries": len(queries), "certified": 0, "escalated": 0, "unproven": 0}
+        tally = {"queries": len(queries), "certified": 0, "escalated": 0, "unproven": 0}
         for s, r, st in eng.search_token_batches(batches()):
-            out.extend((s[i], r[i]) for i in range(s.shape[0]))
             tally["certified"] += int((st == 0).sum())
             tally["escalated"] += int((st == 1).sum()) if eng.exact else 0
             tally["unproven"] += int((st == 2).sum()) + (0 if eng.exact else int((st == 1).sum()))
+            yield [(s[i], r[i]) for i in range(s.shape[0])]
         if eng.refine:
             store.last_exactness = tally
-        return out
 
     def retrieve_batch(self, queries: List[str], top_k: Optional[int] = None) -> List[List[Dict]]:
         """``[retrieve(q) for q in queries]`` for many queries at once: the encoder forwards and scans of the whole list
@@ -193,49 +197,50 @@ class ContextRetriever:
         if col is None:
             raise ValueError("No collection available. Create index first.")
         fetch = k * 2 if self.rerank else k
-        hits = self._search_many(list(queries), fetch)
         per_query: List[List[Dict]] = []
         row_of: Dict[int, int] = {}           # id(chunk dict) -> sidecar row (our store only)
-        if isinstance(hits, dict):            # a duck-typed store's search_batch dict: lists per query
-            ids_l = docs_l = metas_l = None
-            hits = [(np.asarray(hits['distances'][p], dtype=np.float64), (hits['ids'][p], hits['documents'][p],
-                     hits['metadatas'][p] if hits.get('metadatas') else None)) for p in range(len(queries))]
-        else:
-            ids_l, docs_l, metas_l = col.ids, col.documents, col.metadatas
-        for query, (sc, rows) in zip(queries, hits):
-            if ids_l is None:
-                dist, (h_ids, h_docs, h_metas) = sc, rows
-                rows = np.arange(len(h_ids))
-            else:
-                valid = rows >= 0
-                rows, sc = rows[valid], sc[valid]
-                dist = (np.float32(1.0) - sc.astype(np.float32)).astype(np.float64)  # the store's distances, as search() returns them
-                h_ids, h_docs, h_metas = ids_l, docs_l, metas_l
-            if rows.size == 0:
-                logger.warning("No results found for query")
-                per_query.append([])
-                continue
-            if self.distance_metric == 'cosine':                                          # _distance_to_similarity, vectorised (same fp64 ops)
-                d = np.minimum(np.maximum(dist, 0.0), 2.0)
-                score = np.minimum(np.maximum(1.0 - (d * d / 2.0), 0.0), 1.0)
-            else:
-                score = np.array([self._distance_to_similarity(float(x)) for x in dist])
-            keep = score >= self.similarity_threshold
-            chunks = [{'text': h_docs[r], 'score': float(s_), 'distance': float(d_), 'metadata': h_metas[r] if h_metas else {},
-                       'chunk_id': h_ids[r]}
-                      for r, s_, d_, ok in zip(rows.tolist(), score.tolist(), dist.tolist(), keep.tolist()) if ok]
-            if ids_l is not None:
-                for c_, r_ in zip(chunks, [r for r, ok in zip(rows.tolist(), keep.tolist()) if ok]):
-                    row_of[id(c_)] = r_
-            if not chunks:
-                logger.warning(f"No chunks passed similarity threshold of {self.similarity_threshold}")
-                per_query.append([])
-                continue
-            if self.rerank and len(chunks) > k:
-                chunks = self._rerank(query, chunks, k)
-            else:
-                chunks = chunks[:k]
-            per_query.append(chunks)
+        ids_l, docs_l, metas_l = getattr(col, 'ids', None), getattr(col, 'documents', None), getattr(col, 'metadatas', None)
+        queries = list(queries)
+        for piece in self._search_many(queries, fetch):      # one device batch at a time: its dicts are built while the next ones run
+            if isinstance(piece, dict):       # a duck-typed store's search_batch dict: lists per query
+                ids_l = docs_l = metas_l = None
+                piece = [(np.asarray(piece['distances'][p], dtype=np.float64), (piece['ids'][p], piece['documents'][p],
+                          piece['metadatas'][p] if piece.get('metadatas') else None)) for p in range(len(queries))]
+            for sc, rows in piece:
+                query = queries[len(per_query)]
+                if ids_l is None:
+                    dist, (h_ids, h_docs, h_metas) = sc, rows
+                    rows = np.arange(len(h_ids))
+                else:
+                    valid = rows >= 0
+                    rows, sc = rows[valid], sc[valid]
+                    dist = (np.float32(1.0) - sc.astype(np.float32)).astype(np.float64)  # the store's distances, as search() returns them
+                    h_ids, h_docs, h_metas = ids_l, docs_l, metas_l
+                if rows.size == 0:
+                    logger.warning("No results found for query")
+                    per_query.append([])
+                    continue
+                if self.distance_metric == 'cosine':                                          # _distance_to_similarity, vectorised (same fp64 ops)
+                    d = np.minimum(np.maximum(dist, 0.0), 2.0)
+                    score = np.minimum(np.maximum(1.0 - (d * d / 2.0), 0.0), 1.0)
+                else:
+                    score = np.array([self._distance_to_similarity(float(x)) for x in dist])
+                keep = score >= self.similarity_threshold
+                chunks = [{'text': h_docs[r], 'score': float(s_), 'distance': float(d_), 'metadata': h_metas[r] if h_metas else {},
+                           'chunk_id': h_ids[r]}
+                          for r, s_, d_, ok in zip(rows.tolist(), score.tolist(), dist.tolist(), keep.tolist()) if ok]
+                if ids_l is not None:
+                    for c_, r_ in zip(chunks, [r for r, ok in zip(rows.tolist(), keep.tolist()) if ok]):
+                        row_of[id(c_)] = r_
+                if not chunks:
+                    logger.warning(f"No chunks passed similarity threshold of {self.similarity_threshold}")
+                    per_query.append([])
+                    continue
+                if self.rerank and len(chunks) > k:
+                    chunks = self._rerank(query, chunks, k)
+                else:
+                    chunks = chunks[:k]
+                per_query.append(chunks)
         from_index = self.mmr_vectors in ('auto', 'index') and ids_l is not None and hasattr(store, 'rows_f32')
         if self.diversity_penalty > 0 and from_index:
             # the chunks' vectors straight from the index (one gather for the whole batch), then the reference's greedy MMR
