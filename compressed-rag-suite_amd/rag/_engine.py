@@ -62,20 +62,22 @@ class RetrievalEngine:
                     n_ctx: int = 0, enc_lanes: int = 0, search_lanes: int = 0, group_cap: int = 0) -> dict:
         """Lanes, encode groups and buffer sets for an encoder of width `hidden` beside scans of `scan_bytes` per batch (measured
         rules; every explicit argument wins over its rule):
-          * role lanes ('split') over scans of >= 512 MB, else every batch on its own stream;
+          * role lanes ('split') for MiniLM-class encoders always, for bge-class ones over scans of >= 512 MB on one rank; else every
+            batch on its own stream;
           * bge-class encoders (hidden > 384; single rank): 8 batches per encoder forward, 24 buffer sets, 2 encoder + 1 search lane;
-          * MiniLM-class over SHORT scans (< 2 GB: one rank's share of a 4- or 8-GPU C4 step): the 38-launch forward is what the
-            lanes wait for -- 8 batches per forward on ONE encoder lane, 16 buffer sets, and TWO search lanes so that a batch's tail
-            of small kernels and the next batch's sweep overlap (8-GPU rank proxy: 0.255 -> 0.203 ms per batch);
+          * MiniLM-class over SHORT scans (< 2 GB: one rank's share of a 4- or 8-GPU C4 step, C2's 100 k rows): the 38-launch forward
+            is what the lanes wait for -- 32 batches per forward on ONE encoder lane, 64 buffer sets, and TWO search lanes so that a
+            batch's tail of small kernels and the next batch's sweep overlap (8-GPU rank proxy: 0.255 -> 0.185 - 0.19 ms per batch;
+            C2: 398 -> 833 - 846 k q/s -- there the chain WAS the batch);
           * MiniLM-class over long scans (C4 on one GPU): 16 batches per forward on one encoder lane, 32 buffer sets, ONE search lane
             -- 38 kernel boundaries per 16 batches instead of per batch: 47.3 -> 48.6 - 49.0 k q/s on one box (8 per forward over 16
             sets: 48.6 k; a second search lane: 49.8 k, not taken -- consecutive scans then overlap and a trace's per-kernel
             durations stop meaning "one scan").
         group_cap > 0 limits the group (a caller that knows its calls bring fewer batches than a group holds)."""
-        pipelined = lanes == "split" or (lanes == "auto" and encode and scan_bytes >= (512 << 20) and (hidden <= 384 or not multi))
         big, short = hidden > 384, scan_bytes < (2 << 30)
+        pipelined = lanes == "split" or (lanes == "auto" and encode and ((not big) or (scan_bytes >= (512 << 20) and not multi)))
         if encode_group == "auto":
-            encode_group = (8 if (big or short) else 16) if (encode and pipelined) else 1
+            encode_group = (8 if big else 32 if short else 16) if (encode and pipelined) else 1
         encode_group = max(1, int(os.environ.get("CRS_ENCODE_GROUP", encode_group))) if encode else 1
         if group_cap > 0:
             encode_group = min(encode_group, group_cap)

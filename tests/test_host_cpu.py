@@ -434,12 +434,14 @@ def test_plan_layout_rules():
     p = E.plan_layout(384, 8 * gb)                                   # C4 on one GPU
     assert (p["pipelined"], p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (True, 16, 32, 1, 1)
     p = E.plan_layout(384, 1 * gb, multi=True)                       # one rank of an 8-GPU step
-    assert (p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (8, 16, 1, 2)
+    assert (p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (32, 64, 1, 2)
     p = E.plan_layout(768, 2 * gb)                                   # C3 / C5
     assert (p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (8, 24, 2, 1)
     p = E.plan_layout(768, 2 * gb, multi=True)                       # bge-class with N > 1: one stream per batch, as before
     assert p["pipelined"] is False and p["encode_group"] == 1
-    p = E.plan_layout(384, 100 << 20)                                # C2: the chain is the batch
+    p = E.plan_layout(384, 100 << 20)                                # C2: the chain was the batch -- grouped forwards, two search lanes
+    assert (p["pipelined"], p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (True, 32, 64, 1, 2)
+    p = E.plan_layout(768, 100 << 20)                                # bge-class over a small store: one stream per batch, as before
     assert p["pipelined"] is False and p["encode_group"] == 1 and p["n_ctx"] == 8
     p = E.plan_layout(384, 8 * gb, group_cap=4)                      # a caller whose calls bring four batches
     assert p["encode_group"] == 4 and p["n_ctx"] == 8
