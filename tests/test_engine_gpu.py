@@ -109,3 +109,28 @@ def test_cu_masked_stream_runs_the_same_search(world):
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
     with pytest.raises(nat.NativeError):
         nat.cu_masked_stream(250, 64, view.slab.device)
+
+
+def test_no_batches_and_an_int8_shard(world, cuda):
+    """An empty iterator yields nothing; an int8 shard (scales, empirical exactness) behaves the same under groups."""
+    import torch
+    from rag import _native as nat
+    from rag._engine import RetrievalEngine, ShardView
+    enc, view = world
+    eng = RetrievalEngine(enc, view, QB, SEQ, K, lanes="split", encode_group=4, n_ctx=8)
+    assert list(eng.search_token_batches(iter([]))) == []
+    n = 30_000
+    pd = nat.padded_dim(DIM, nat.SLAB_I8)
+    slab = torch.zeros((n, pd), dtype=torch.int8, device=cuda)
+    scales = torch.empty(n, dtype=torch.float32, device=cuda)
+    shadow = torch.empty((n, DIM), dtype=torch.float32, device=cuda)
+    err = torch.zeros(1, dtype=torch.float32, device=cuda)
+    nat.slab_append_f32(view.shadow[:n].contiguous(), slab, 0, nat.SLAB_I8, scales=scales, shadow=shadow, row_err=err)
+    v8 = ShardView(slab, scales, shadow, n, DIM, nat.SLAB_I8, 0, float(err.item()))
+    plain = RetrievalEngine(enc, v8, QB, SEQ, K, lanes="batch", encode_group=1, n_ctx=2)
+    grouped = RetrievalEngine(enc, v8, QB, SEQ, K, lanes="split", encode_group=4, n_ctx=8, enc_lanes=2, search_lanes=1)
+    batches = _batches(7, 6, seed=9)
+    a, b = _run(plain, batches), _run(grouped, batches)
+    same = sum(int((x[1] == y[1]).sum()) for x, y in zip(a, b))
+    assert same >= 0.97 * sum(x[1].size for x in a)
+    assert max(float(np.abs(x[0] - y[0]).max()) for x, y in zip(a, b)) < 1e-4
