@@ -417,6 +417,83 @@ __global__ __launch_bounds__(NW * 64) void attention_seq32_kernel(const _Float16
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: query-length sequences (<= 16 tokens, head_dim 32 / 64): one WAVE per (sequence, head), no workgroup barrier.
+// The blocked kernel gives a 64-query block to four waves: at 16 tokens three of them idle through the staging and the barriers
+// (bge-base over eight C3 batches: 24 576 (sequence, head) units = 24 576 workgroups; 163 us per layer in the mix).  Here a wave
+// loads its unit's Q and K rows as MFMA fragments straight from global memory (16-byte loads), S^T = K Q^T is HD / 32 MFMAs of
+// 16x16x32, the softmax over the 16 keys is four values per lane + two cross-lane steps, V goes through a wave-private 2.5 KB
+// LDS tile to become V^T fragments, O^T = V^T P^T is HD / 16 MFMAs of 16x16x16 with P^T straight from the score registers.
+template <int HD>
+__global__ __launch_bounds__(256) void attention_short_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ lens,
+                                                             _Float16* __restrict__ ctx, int seq, int hidden, int n_units) {
+  constexpr int KS = HD / 32, NT = HD / 16, VROW = 20;        // V^T rows of 16 keys + 4 halves of padding (8-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) _Float16 sVt[4][HD * VROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= n_units) return;                                 // (no workgroup barrier below)
+  const int heads = hidden / HD;
+  const int b = unit / heads, h = unit % heads;
+  const int len = min(max(lens[b], 1), seq);
+  const size_t row_stride = (size_t)3 * hidden;
+  const _Float16* base = qkv + (size_t)b * seq * row_stride + h * HD;
+  const float c = 1.44269504088896341f / sqrtf((float)HD);     // log2(e) / sqrt(hd)
+  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f};                             // S^T: rows = keys 4 g + i, column = query lr
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const _Float16* rowp = base + (size_t)lr * row_stride + ks * 32 + g * 8;
+    const f16x8 qf = (lr < seq) ? *reinterpret_cast<const f16x8*>(rowp) : z8;
+    const f16x8 kf = (lr < seq) ? *reinterpret_cast<const f16x8*>(rowp + hidden) : z8;
+    sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, sc, 0, 0, 0);
+  }
+  // V rows -> V^T in this wave's LDS tile: lane (key = lane >> 2, quarter = lane & 3) takes HD / 4 head-dim elements of its key
+  {
+    const int key = lane >> 2, qt = lane & 3;
+    constexpr int PER = HD / 4;                                // 16 (head_dim 64) or 8 (32) elements per lane
+#pragma unroll
+    for (int u = 0; u < PER / 8; ++u) {
+      const f16x8 v = (key < seq) ? *reinterpret_cast<const f16x8*>(base + (size_t)key * row_stride + 2 * hidden + qt * PER + u * 8) : z8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sVt[wave][(qt * PER + u * 8 + e) * VROW + key] = v[e];
+    }
+  }
+  // softmax over the keys of query lr (keys >= len masked; key 0 is always real, so the maximum is finite)
+  float mx = -1e30f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (4 * g + i >= len) sc[i] = -1e30f;
+    mx = fmaxf(mx, sc[i]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float mn = mx * c;
+  float rs = 0.f;
+  f16x4 pf;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float p = __builtin_amdgcn_exp2f(fmaf(sc[i], c, -mn));
+    rs += p;
+    pf[i] = (_Float16)p;
+  }
+  rs += __shfl_xor(rs, 16);
+  rs += __shfl_xor(rs, 32);
+  __builtin_amdgcn_wave_barrier();                             // the wave's V^T stores precede its fragment reads (LDS ops of one wave stay in order)
+  const float inv = 1.0f / rs;
+  // (every lane multiplies: as A operand lane lr is head-dim row 16 n + lr of V^T, whatever the sequence length; only the store
+  // -- column = query lr -- depends on it)
+  _Float16* dst = ctx + ((size_t)b * seq + (lr < seq ? lr : 0)) * hidden + h * HD;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const f16x4 vf = *reinterpret_cast<const f16x4*>(&sVt[wave][(n * 16 + lr) * VROW + 4 * g]);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o, 0, 0, 0);
+    const f16x4 ov = {(_Float16)(o[0] * inv), (_Float16)(o[1] * inv), (_Float16)(o[2] * inv), (_Float16)(o[3] * inv)};
+    if (lr < seq) *reinterpret_cast<f16x4*>(dst + n * 16 + 4 * g) = ov;
+  }
+}
+
 }  // namespace
 
 int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int batch, int seq, int hidden,
@@ -425,6 +502,14 @@ int attention_launch(const _Float16* qkv, const int* lens, _Float16* ctx, int ba
   // whole sequence per workgroup when it is long enough to matter and short enough for LDS (CRS_ATTN_SEQ=0: off)
   static int seq_on = -1;
   if (seq_on < 0) { const char* e = getenv("CRS_ATTN_SEQ"); seq_on = (e && e[0] == '0') ? 0 : 1; }
+  static int short_on = -1;   // CRS_ATTN_SHORT=0: query-length sequences on the blocked kernel (A/B runs)
+  if (short_on < 0) { const char* e = getenv("CRS_ATTN_SHORT"); short_on = (e && e[0] == '0') ? 0 : 1; }
+  if (short_on && seq <= 16 && (hd == 32 || hd == 64)) {
+    const int units = heads * batch;
+    if (hd == 32) hipLaunchKernelGGL((attention_short_kernel<32>), dim3((units + 3) / 4), dim3(256), 0, stream, qkv, lens, ctx, seq, hidden, units);
+    else hipLaunchKernelGGL((attention_short_kernel<64>), dim3((units + 3) / 4), dim3(256), 0, stream, qkv, lens, ctx, seq, hidden, units);
+    return (int)hipGetLastError();
+  }
   if (seq_on && seq > 64) {
     dim3 g2(heads * batch);
     auto launch = [&](auto kernel, int threads, int lds) -> int {

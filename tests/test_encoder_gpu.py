@@ -67,6 +67,10 @@ def test_gemm_vs_torch_fp32(cuda, mode, m, n, k):
     # C3's query batch: 4096 tokens of bge-base -- QKV / FFN-up on the phase-scheduled 256 x 256 kernel, the two N = 768
     # projections on its split-K form (3 fp32 slabs summed by the LayerNorm kernel)
     ("bge-256x16", er.BGE_BASE, 35, 256, 16),
+    # query-length sequences on the one-wave-per-(sequence, head) attention kernel (round 3): full 16 tokens, fewer (padded rows
+    # of the 16 x 16 tiles), ragged lengths inside them; both head widths
+    ("minilm-9x16", er.MINILM_L6, 36, 9, 16), ("minilm-5x7", er.MINILM_L6, 37, 5, 7), ("bge-3x12", er.BGE_BASE, 38, 3, 12),
+    ("minilm-70x3", er.MINILM_L6, 39, 70, 3),
 ])
 def test_encoder_matches_oracle(cuda, name, cfg, seed, batch, seq):
     import torch
