@@ -401,7 +401,8 @@ def main():
     # buffer sets in flight: the engine's rule (8; 16 / 24 with encode groups) unless --streams says otherwise
     n_ctx = RetrievalEngine.plan_layout(shape.hidden, rows * pd * (1 if slab_type == nat.SLAB_I8 else 2), encode=not args.scan_only, multi=multi,
                                         lanes=args.lanes, encode_group=args.encode_group if args.encode_group > 0 else "auto",
-                                        n_ctx=args.streams, enc_lanes=args.enc_lanes, search_lanes=args.search_lanes)["n_ctx"]
+                                        n_ctx=args.streams, enc_lanes=args.enc_lanes, search_lanes=args.search_lanes,
+                                        batch_tokens=(qb // (world if (strong and multi and want_shard) else 1)) * QUERY_TOKENS)["n_ctx"]
     # Query set: R distinct queries (>= --recall-queries, a whole number of batches; the first n_ctx batches are the ones the
     # timed loop keeps in flight).  strong: every rank holds the SAME global batches; weak: per-rank queries.
     n_batches = max(n_ctx, -(-max(args.recall_queries, 1) // qb)) if strong else n_ctx

@@ -59,12 +59,13 @@ class _Group:
 class RetrievalEngine:
     @staticmethod
     def plan_layout(hidden: int, scan_bytes: int, *, encode: bool = True, multi: bool = False, lanes: str = "auto", encode_group="auto",
-                    n_ctx: int = 0, enc_lanes: int = 0, search_lanes: int = 0, group_cap: int = 0) -> dict:
+                    n_ctx: int = 0, enc_lanes: int = 0, search_lanes: int = 0, group_cap: int = 0, batch_tokens: int = 0) -> dict:
         """Lanes, encode groups and buffer sets for an encoder of width `hidden` beside scans of `scan_bytes` per batch (measured
         rules; every explicit argument wins over its rule):
           * role lanes ('split') for MiniLM-class encoders always, for bge-class ones over scans of >= 512 MB on one rank; else every
             batch on its own stream;
-          * bge-class encoders (hidden > 384; single rank): 8 batches per encoder forward, 24 buffer sets, 2 encoder + 1 search lane;
+          * bge-class encoders (hidden > 384; single rank): 8 batches per encoder forward over 24 buffer sets (16 over 32 when a
+            batch is < 4096 tokens), 2 encoder + 1 search lane;
           * MiniLM-class over SHORT scans (< 2 GB: one rank's share of a 4- or 8-GPU C4 step, C2's 100 k rows): the 38-launch forward
             is what the lanes wait for -- 32 batches per forward on ONE encoder lane, 64 buffer sets, and TWO search lanes so that a
             batch's tail of small kernels and the next batch's sweep overlap (8-GPU rank proxy: 0.255 -> 0.185 - 0.19 ms per batch;
@@ -77,12 +78,13 @@ class RetrievalEngine:
         big, short = hidden > 384, scan_bytes < (2 << 30)
         pipelined = lanes == "split" or (lanes == "auto" and encode and ((not big) or (scan_bytes >= (512 << 20) and not multi)))
         if encode_group == "auto":
-            encode_group = (8 if big else 32 if short else 16) if (encode and pipelined) else 1
+            big_g = 16 if 0 < batch_tokens < 4096 else 8      # (C5's 1024-token batches: 38.9 -> 39.7 k q/s with 16; C3's 4096: 8 is best)
+            encode_group = (big_g if big else 32 if short else 16) if (encode and pipelined) else 1
         encode_group = max(1, int(os.environ.get("CRS_ENCODE_GROUP", encode_group))) if encode else 1
         if group_cap > 0:
             encode_group = min(encode_group, group_cap)
         if n_ctx <= 0:
-            n_ctx = 8 if encode_group == 1 else (3 * encode_group if big else 2 * encode_group)
+            n_ctx = 8 if encode_group == 1 else (3 * encode_group if (big and encode_group <= 8) else 2 * encode_group)
         while n_ctx % encode_group:
             encode_group -= 1
         if pipelined:
@@ -134,7 +136,8 @@ class RetrievalEngine:
         scan_bytes = view.n * self.pd * (1 if view.slab_type == nat.SLAB_I8 else 2)
         hidden = encoder.shape.hidden if encoder is not None else view.dim
         plan = self.plan_layout(hidden, scan_bytes, encode=self.encode, multi=self.multi, lanes=lanes, encode_group=encode_group,
-                                n_ctx=int(n_ctx), enc_lanes=enc_lanes, search_lanes=search_lanes, group_cap=int(group_cap))
+                                n_ctx=int(n_ctx), enc_lanes=enc_lanes, search_lanes=search_lanes, group_cap=int(group_cap),
+                                batch_tokens=self.q_loc * self.seq)
         self.pipelined, self.enc_group, self.n_ctx = plan["pipelined"], plan["encode_group"], plan["n_ctx"]
         self.n_enc, self.n_srch = plan["n_enc"], plan["n_srch"]
         # <= 48 KB kernel forms of the encoder (they can start beside a scan's resident workgroups): with role lanes always;

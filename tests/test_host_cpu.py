@@ -437,6 +437,8 @@ def test_plan_layout_rules():
     assert (p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (32, 64, 1, 2)
     p = E.plan_layout(768, 2 * gb)                                   # C3 / C5
     assert (p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (8, 24, 2, 1)
+    p = E.plan_layout(768, 8 * gb, batch_tokens=1024)                # C5: 64-query batches of a bge-class encoder
+    assert (p["encode_group"], p["n_ctx"], p["n_enc"], p["n_srch"]) == (16, 32, 2, 1)
     p = E.plan_layout(768, 2 * gb, multi=True)                       # bge-class with N > 1: one stream per batch, as before
     assert p["pipelined"] is False and p["encode_group"] == 1
     p = E.plan_layout(384, 100 << 20)                                # C2: the chain was the batch -- grouped forwards, two search lanes
