@@ -374,7 +374,9 @@ int crs_refine_f32(const float* q32_dev, int nq, int dim, const float* shadow_de
 }
 
 // exactness workspace: [threshold f32 [nq] | counter i32 [nq] | row lists i64 [nq, cap]]
-static size_t exact_lists_off(int nq) { return 2 * align_up((size_t)nq * 4, 256); }
+// exactness workspace: [thresholds | counters | the escalation kernel's blocks-through counter (256 B) | lists]
+static size_t exact_done_off(int nq) { return 2 * align_up((size_t)nq * 4, 256); }
+static size_t exact_lists_off(int nq) { return exact_done_off(nq) + 256; }
 size_t crs_exact_workspace_bytes(int nq, int cap) {
   return (nq > 0 && cap > 0) ? exact_lists_off(nq) + (size_t)nq * cap * 8 : 0;
 }
@@ -403,7 +405,8 @@ int crs_refine_f32_cert(const float* q32_dev, const void* q16_dev, int nq, int d
   const int e = crs::refine_cert_launch(q32_dev, reinterpret_cast<const _Float16*>(q16_dev), nq, dim, crs_row_elems(dim, slab_type),
                                         slab_type, shadow_dev, n_rows, id_base, cand_ids_dev, cand_scores_dev, k_in, k_out, row_err_max,
                                         out_scores_dev, out_ids_dev, status_dev, reinterpret_cast<float*>(ws),
-                                        reinterpret_cast<int*>(ws + align_up((size_t)nq * 4, 256)), (hipStream_t)stream);
+                                        reinterpret_cast<int*>(ws + align_up((size_t)nq * 4, 256)), reinterpret_cast<int*>(ws + exact_done_off(nq)),
+                                        (hipStream_t)stream);
   return e ? hip_fail((hipError_t)e, "refine_f32_cert launch") : CRS_OK;
 }
 
@@ -421,6 +424,7 @@ int crs_escalate_exact(const float* q32_dev, const void* q16_dev, int nq, int di
   const int e = crs::escalate_launch(q32_dev, reinterpret_cast<const _Float16*>(q16_dev), nq, dim, crs_row_elems(dim, slab_type), slab_type,
                                      slab_dev, scales_dev, shadow_dev, n_rows, id_base, k_out, out_scores_dev, out_ids_dev, status_dev,
                                      reinterpret_cast<const float*>(ws), reinterpret_cast<int*>(ws + align_up((size_t)nq * 4, 256)),
+                                     reinterpret_cast<int*>(ws + exact_done_off(nq)),
                                      reinterpret_cast<int64_t*>(ws + exact_lists_off(nq)), cap, device_cus(), (hipStream_t)stream);
   if (e == -1) return fail(CRS_EINVAL, "unsupported padded dimension");
   return e ? hip_fail((hipError_t)e, "escalate launch") : CRS_OK;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void refine_cert_kernel(const float* __restric
                                                          int64_t id_base, const int64_t* __restrict__ cand,
                                                          const float* __restrict__ cand_s, int k_in, int k_out, float err_rows,
                                                          float err_arith, float* __restrict__ out_s, int64_t* __restrict__ out_i,
-                                                         int* __restrict__ status, float* __restrict__ ws_thr, int* __restrict__ ws_cnt) {
+                                                         int* __restrict__ status, float* __restrict__ ws_thr, int* __restrict__ ws_cnt, int* __restrict__ ws_done) {
   __shared__ float sh_s[64];
   __shared__ int64_t sh_i[64];
   __shared__ float red[4][3];
@@ -160,85 +160,22 @@ __global__ __launch_bounds__(256) void refine_cert_kernel(const float* __restric
     status[qi] = st;
     ws_thr[qi] = kth - eps;
     ws_cnt[qi] = 0;
+    if (qi == 0) *ws_done = 0;       // the escalation kernel's "blocks through" counter
   }
 }
 
-// ---- escalation, stage 1: list every row whose slab score reaches the query's threshold ----------------------------
-// Plain fp16 MFMA sweep with fragment-shaped global loads (a rare path: no LDS staging, no selection state).
+// ---- escalation (one launch): stage 1 lists every row whose slab score reaches the query's threshold, stage 2 re-ranks the lists ---
+// Stage 1: plain fp16 MFMA sweep with fragment-shaped global loads (a rare path: no LDS staging, no selection state).
 // KS = pdim / 128.  A = 16 slab rows, B = 16 uncertified queries (resident in VGPRs for the sweep), D[row][query].
-template <int KS, bool I8>
-__global__ __launch_bounds__(256) void collect_above_kernel(const _Float16* __restrict__ q16, int nq, const void* __restrict__ slab_,
-                                                           const float* __restrict__ scales, int n_rows, int64_t id_base,
-                                                           const int* __restrict__ status, const float* __restrict__ thr,
-                                                           int cap, int* __restrict__ counts, int64_t* __restrict__ lists) {
-  constexpr int D = KS * 128, kSteps = D / 32;
-  __shared__ int need[1024];
-  __shared__ int n_need;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int lr = lane & 15, kq = lane >> 4;
-  if (t == 0) n_need = 0;
-  __syncthreads();
-  for (int q0 = 0; q0 < nq; q0 += 1024) {          // uncertified queries of this chunk of the batch, in any order
-    if (q0) { __syncthreads(); if (t == 0) n_need = 0; __syncthreads(); }
-    for (int q = q0 + t; q < nq && q < q0 + 1024; q += 256)
-      if (status[q] == 1) need[atomicAdd(&n_need, 1)] = q;
-    __syncthreads();
-    const int nn = n_need;
-    for (int g = 0; g < nn; g += 16) {
-      const int myq = (g + lr < nn) ? need[g + lr] : -1;
-      f16x8 qf[kSteps];
-      const _Float16* qrow = q16 + (size_t)(myq < 0 ? 0 : myq) * D + kq * 8;
-#pragma unroll
-      for (int s = 0; s < kSteps; ++s) qf[s] = *reinterpret_cast<const f16x8*>(qrow + s * 32);
-      const float th = myq < 0 ? __builtin_huge_valf() : thr[myq];
-      const int n_tiles = (n_rows + 15) / 16;
-      for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-        const int row = tile * 16 + lr;
-        const int crow = row < n_rows ? row : n_rows - 1;
-        f16x8 af[kSteps];
-        if (I8) {
-          const int8_t* arow = reinterpret_cast<const int8_t*>(slab_) + (size_t)crow * D + kq * 8;
-#pragma unroll
-          for (int s = 0; s < kSteps; ++s) {
-            const int2 raw = *reinterpret_cast<const int2*>(arow + s * 32);
-            const int8_t* b8 = reinterpret_cast<const int8_t*>(&raw);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) af[s][e] = (_Float16)(float)b8[e];
-          }
-        } else {
-          const _Float16* arow = reinterpret_cast<const _Float16*>(slab_) + (size_t)crow * D + kq * 8;
-#pragma unroll
-          for (int s = 0; s < kSteps; ++s) af[s] = *reinterpret_cast<const f16x8*>(arow + s * 32);
-        }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < kSteps; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], qf[s], acc, 0, 0, 0);
-        // lane (query column lr, quad kq) holds rows tile * 16 + 4 kq + i
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rr = tile * 16 + 4 * kq + i;
-          float sc = acc[i];
-          if (I8) sc *= scales[rr < n_rows ? rr : n_rows - 1];
-          if (myq >= 0 && rr < n_rows && sc >= th) {
-            const int p = atomicAdd(&counts[myq], 1);
-            if (p < cap) lists[(size_t)myq * cap + p] = (int64_t)rr + id_base;
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---- escalation, stage 2: fp32 re-rank of an escalated query's list ------------------------------------------------
-// One 256-thread workgroup per query; queries with status != 1 return at once.  Dynamic LDS: cap * 12 bytes.
-__global__ __launch_bounds__(256) void refine_list_kernel(const float* __restrict__ q32, int dim, const float* __restrict__ shadow,
-                                                         int64_t n_rows, int64_t id_base, int* __restrict__ status,
-                                                         const int* __restrict__ counts, const int64_t* __restrict__ lists, int cap,
-                                                         int k_out, float* __restrict__ out_s, int64_t* __restrict__ out_i) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int qi = blockIdx.x;
-  if (status[qi] != 1) return;
-  const int n = counts[qi];
+// Stage 2 (fp32 re-rank of an escalated query's list against the shadow) is done by the LAST block through stage 1 -- release
+// fence + counter, acquire fence, no spinning -- one query after the other: escalations are rare, and when NO query needs one
+// every block leaves at the top (status is read-only until stage 2), so the common case is a single empty launch instead of
+// two.  Dynamic LDS: max(cap * 12, 4 KB) bytes -- stage 1's list of uncertified queries and stage 2's (score, id) list share it.
+__device__ void refine_list_one(int qi, char* smem, const float* __restrict__ q32, int dim, const float* __restrict__ shadow,
+                                int64_t n_rows, int64_t id_base, int* __restrict__ status, const int* __restrict__ counts,
+                                const int64_t* __restrict__ lists, int cap, int k_out, float* __restrict__ out_s,
+                                int64_t* __restrict__ out_i) {
+  const int n = __hip_atomic_load(&counts[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (n > cap) {                       // more rows in the band than the list holds: the caller repeats with a larger cap
     if (t == 0) status[qi] = 2;
@@ -286,17 +223,115 @@ __global__ __launch_bounds__(256) void refine_list_kernel(const float* __restric
     }
     if (rank < k_out) { out_s[(size_t)qi * k_out + rank] = s; out_i[(size_t)qi * k_out + rank] = id; }
   }
+  __syncthreads();                     // the list's LDS is reused by the next query
+}
+
+template <int KS, bool I8>
+__global__ __launch_bounds__(256) void escalate_kernel(const float* __restrict__ q32, const _Float16* __restrict__ q16, int nq, int dim,
+                                                      const void* __restrict__ slab_, const float* __restrict__ scales,
+                                                      const float* __restrict__ shadow, int n_rows, int64_t id_base,
+                                                      int* __restrict__ status, const float* __restrict__ thr, int cap,
+                                                      int* __restrict__ counts, int64_t* __restrict__ lists, int* __restrict__ done,
+                                                      int k_out, float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  constexpr int D = KS * 128, kSteps = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char esc_smem[];
+  int* need = reinterpret_cast<int*>(esc_smem);      // stage 1: up to 1024 uncertified queries of a chunk of the batch
+  __shared__ int n_need;
+  __shared__ int is_last;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, kq = lane >> 4;
+  bool any = false;
+  if (t == 0) n_need = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < nq; q0 += 1024) {          // uncertified queries of this chunk of the batch, in any order
+    if (q0) { __syncthreads(); if (t == 0) n_need = 0; __syncthreads(); }
+    for (int q = q0 + t; q < nq && q < q0 + 1024; q += 256)
+      if (status[q] == 1) need[atomicAdd(&n_need, 1)] = q;
+    __syncthreads();
+    const int nn = n_need;
+    any = any || nn > 0;
+    for (int g = 0; g < nn; g += 16) {
+      const int myq = (g + lr < nn) ? need[g + lr] : -1;
+      f16x8 qf[kSteps];
+      const _Float16* qrow = q16 + (size_t)(myq < 0 ? 0 : myq) * D + kq * 8;
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) qf[s] = *reinterpret_cast<const f16x8*>(qrow + s * 32);
+      const float th = myq < 0 ? __builtin_huge_valf() : thr[myq];
+      const int n_tiles = (n_rows + 15) / 16;
+      for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + lr;
+        const int crow = row < n_rows ? row : n_rows - 1;
+        f16x8 af[kSteps];
+        if (I8) {
+          const int8_t* arow = reinterpret_cast<const int8_t*>(slab_) + (size_t)crow * D + kq * 8;
+#pragma unroll
+          for (int s = 0; s < kSteps; ++s) {
+            const int2 raw = *reinterpret_cast<const int2*>(arow + s * 32);
+            const int8_t* b8 = reinterpret_cast<const int8_t*>(&raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[s][e] = (_Float16)(float)b8[e];
+          }
+        } else {
+          const _Float16* arow = reinterpret_cast<const _Float16*>(slab_) + (size_t)crow * D + kq * 8;
+#pragma unroll
+          for (int s = 0; s < kSteps; ++s) af[s] = *reinterpret_cast<const f16x8*>(arow + s * 32);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], qf[s], acc, 0, 0, 0);
+        // lane (query column lr, quad kq) holds rows tile * 16 + 4 kq + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = tile * 16 + 4 * kq + i;
+          float sc = acc[i];
+          if (I8) sc *= scales[rr < n_rows ? rr : n_rows - 1];
+          if (myq >= 0 && rr < n_rows && sc >= th) {
+            const int p = atomicAdd(&counts[myq], 1);
+            if (p < cap) lists[(size_t)myq * cap + p] = (int64_t)rr + id_base;
+          }
+        }
+      }
+    }
+  }
+  if (!any) return;      // nothing to escalate: every block sees the same (read-only) status words and leaves here
+  // ---- stage 2 by the last block through stage 1 (cdna_hip_programming.md, in-launch hand-off: stores -> vmcnt(0) -> barrier ->
+  // lane 0: agent release fence -> vmcnt(0) -> relaxed agent fetch_add; the reader: agent acquire fence -> barrier -> reads)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = (__hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *done = 0;           // (refine_cert_kernel zeroes it as well, ahead of every escalation)
+  }
+  __syncthreads();
+  for (int q = 0; q < nq; ++q)
+    if (status[q] == 1)  // (block-uniform: status[q] is written below only for q itself, behind a barrier)
+      refine_list_one(q, esc_smem, q32, dim, shadow, (int64_t)n_rows, id_base, status, counts, lists, cap, k_out, out_s, out_i);
 }
 
 template <int KS>
-void launch_collect(bool i8, unsigned grid, hipStream_t st, const _Float16* q16, int nq, const void* slab, const float* scales,
-                    int n_rows, int64_t id_base, const int* status, const float* thr, int cap, int* counts, int64_t* lists) {
+int launch_escalate(bool i8, unsigned grid, size_t lds, hipStream_t st, const float* q32, const _Float16* q16, int nq, int dim, const void* slab,
+                    const float* scales, const float* shadow, int n_rows, int64_t id_base, int* status, const float* thr, int cap, int* counts,
+                    int64_t* lists, int* done, int k_out, float* out_s, int64_t* out_i) {
+  const void* kernel = i8 ? reinterpret_cast<const void*>(&escalate_kernel<KS, true>) : reinterpret_cast<const void*>(&escalate_kernel<KS, false>);
+  if (lds > 48 * 1024) {     // beyond the default dynamic-LDS limit (up to the CU's 160 KiB: cap <= 13312)
+    const hipError_t ae = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ae != hipSuccess) return (int)ae;
+  }
   if (i8)
-    hipLaunchKernelGGL((collect_above_kernel<KS, true>), dim3(grid), dim3(256), 0, st, q16, nq, slab, scales, n_rows, id_base, status,
-                       thr, cap, counts, lists);
+    hipLaunchKernelGGL((escalate_kernel<KS, true>), dim3(grid), dim3(256), lds, st, q32, q16, nq, dim, slab, scales, shadow, n_rows, id_base,
+                       status, thr, cap, counts, lists, done, k_out, out_s, out_i);
   else
-    hipLaunchKernelGGL((collect_above_kernel<KS, false>), dim3(grid), dim3(256), 0, st, q16, nq, slab, scales, n_rows, id_base, status,
-                       thr, cap, counts, lists);
+    hipLaunchKernelGGL((escalate_kernel<KS, false>), dim3(grid), dim3(256), lds, st, q32, q16, nq, dim, slab, scales, shadow, n_rows, id_base,
+                       status, thr, cap, counts, lists, done, k_out, out_s, out_i);
+  return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -312,16 +347,16 @@ float exact_err_rows_bound(int dim, int slab_type) {
 
 int refine_cert_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const float* shadow,
                        int64_t n_rows, int64_t id_base, const int64_t* cand, const float* cand_s, int k_in, int k_out,
-                       float err_rows, float* out_s, int64_t* out_i, int* status, float* ws_thr, int* ws_cnt, hipStream_t stream) {
+                       float err_rows, float* out_s, int64_t* out_i, int* status, float* ws_thr, int* ws_cnt, int* ws_done, hipStream_t stream) {
   if (nq <= 0) return 0;
   hipLaunchKernelGGL(refine_cert_kernel, dim3(nq), dim3(256), 0, stream, q32, q16, dim, pdim, slab_type == 1 ? 1 : 0, shadow, n_rows,
-                     id_base, cand, cand_s, k_in, k_out, err_rows, exact_err_arith(dim, pdim), out_s, out_i, status, ws_thr, ws_cnt);
+                     id_base, cand, cand_s, k_in, k_out, err_rows, exact_err_arith(dim, pdim), out_s, out_i, status, ws_thr, ws_cnt, ws_done);
   return (int)hipGetLastError();
 }
 
 int escalate_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const void* slab,
                     const float* scales, const float* shadow, int64_t n_rows, int64_t id_base, int k_out, float* out_s,
-                    int64_t* out_i, int* status, const float* ws_thr, int* ws_cnt, int64_t* ws_lists, int cap, int cus,
+                    int64_t* out_i, int* status, const float* ws_thr, int* ws_cnt, int* ws_done, int64_t* ws_lists, int cap, int cus,
                     hipStream_t stream) {
   if (nq <= 0) return 0;
   const bool i8 = slab_type == 1;
@@ -329,27 +364,21 @@ int escalate_launch(const float* q32, const _Float16* q16, int nq, int dim, int 
   int64_t g = (tiles + 3) / 4;
   const int64_t gmax = (int64_t)(cus > 0 ? cus : 256) * 4;
   const unsigned grid = (unsigned)(g < gmax ? (g < 1 ? 1 : g) : gmax);
+  const size_t lds = (size_t)cap * 12 > 4096 ? (size_t)cap * 12 : 4096;
+#define CRS_ESC(KS_) return launch_escalate<KS_>(i8, grid, lds, stream, q32, q16, nq, dim, slab, scales, shadow, (int)n_rows, id_base, status, \
+                                                  ws_thr, cap, ws_cnt, ws_lists, ws_done, k_out, out_s, out_i)
   switch (pdim / 128) {
-    case 1: launch_collect<1>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
-    case 2: launch_collect<2>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
-    case 3: launch_collect<3>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
-    case 4: launch_collect<4>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
-    case 5: launch_collect<5>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
-    case 6: launch_collect<6>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
-    case 7: launch_collect<7>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
-    case 8: launch_collect<8>(i8, grid, stream, q16, nq, slab, scales, (int)n_rows, id_base, status, ws_thr, cap, ws_cnt, ws_lists); break;
+    case 1: CRS_ESC(1);
+    case 2: CRS_ESC(2);
+    case 3: CRS_ESC(3);
+    case 4: CRS_ESC(4);
+    case 5: CRS_ESC(5);
+    case 6: CRS_ESC(6);
+    case 7: CRS_ESC(7);
+    case 8: CRS_ESC(8);
     default: return -1;
   }
-  int e = (int)hipGetLastError();
-  if (e) return e;
-  if ((size_t)cap * 12 > 48 * 1024) {     // beyond the default dynamic-LDS limit (up to the CU's 160 KiB: cap <= 13312)
-    const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(refine_list_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, cap * 12);
-    if (ae != hipSuccess) return (int)ae;
-  }
-  hipLaunchKernelGGL(refine_list_kernel, dim3(nq), dim3(256), (size_t)cap * 12, stream, q32, dim, shadow, n_rows, id_base, status,
-                     ws_cnt, ws_lists, cap, k_out, out_s, out_i);
-  return (int)hipGetLastError();
+#undef CRS_ESC
 }
 
 }  // namespace crs

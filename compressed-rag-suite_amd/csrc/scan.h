@@ -89,10 +89,10 @@ float exact_err_arith(int dim, int pdim);
 float exact_err_rows_bound(int dim, int slab_type);
 int refine_cert_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const float* shadow,
                        int64_t n_rows, int64_t id_base, const int64_t* cand, const float* cand_s, int k_in, int k_out,
-                       float err_rows, float* out_s, int64_t* out_i, int* status, float* ws_thr, int* ws_cnt, hipStream_t stream);
+                       float err_rows, float* out_s, int64_t* out_i, int* status, float* ws_thr, int* ws_cnt, int* ws_done, hipStream_t stream);
 int escalate_launch(const float* q32, const _Float16* q16, int nq, int dim, int pdim, int slab_type, const void* slab,
                     const float* scales, const float* shadow, int64_t n_rows, int64_t id_base, int k_out, float* out_s,
-                    int64_t* out_i, int* status, const float* ws_thr, int* ws_cnt, int64_t* ws_lists, int cap, int cus,
+                    int64_t* out_i, int* status, const float* ws_thr, int* ws_cnt, int* ws_done, int64_t* ws_lists, int cap, int cus,
                     hipStream_t stream);
 
 }  // namespace crs

@@ -135,7 +135,7 @@ def test_argument_validation_without_gpu():
     assert lib.crs_merge_topk(None, None, 1, 1, 1, 1, None, None, None) == -1
     assert lib.crs_slab_append_f32(None, 5, 384, 7, None, None, None, 0, None, None) == -1
     # exactness workspace: [thr | count | lists], and the analytic row-error bounds (fp16: 2^-11 relative; int8: 1/254 per element)
-    assert lib.crs_exact_workspace_bytes(64, 1024) == 2 * 256 + 64 * 1024 * 8
+    assert lib.crs_exact_workspace_bytes(64, 1024) == 2 * 256 + 256 + 64 * 1024 * 8     # thresholds | counters | blocks-through counter | lists
     assert lib.crs_exact_workspace_bytes(0, 1024) == 0
     assert 4.88e-4 < lib.crs_exact_row_error_bound(384, 0) < 4.95e-4
     assert abs(lib.crs_exact_row_error_bound(768, 1) - 768 ** 0.5 / 254) < 1e-4
