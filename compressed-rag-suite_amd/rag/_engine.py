@@ -152,9 +152,9 @@ class RetrievalEngine:
                 self.enc_streams = [nat.cu_masked_stream(i * self.enc_cus, self.enc_cus, self.dev) for i in range(self.n_enc)]
             else:
                 self.enc_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_enc)]
-            # (search lanes, or the encoder lanes, as high-priority streams: measured null on C3 / C4 / C5 / the 8-GPU rank proxy, tools/r3_prio.sh)
+            # (search lanes, or the encoder lanes, as high-priority streams: measured null on C3 / C4 / C5 / the 8-GPU rank proxy)
             # (the chip partitioned by CU masks -- searches on 224 / 192 / 160 CUs, encoders on the rest -- loses on C5 and C3, where
-            # the bge forwards need far more than the rest, and is neutral on C4: tools/r3_part.sh)
+            # the bge forwards need far more than the rest, and is neutral on C4: DESIGN.md section 4)
             self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_srch)]
         else:
             self.enc_streams = self.srch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_ctx)]
