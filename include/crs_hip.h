@@ -116,8 +116,8 @@ int crs_refine_f32(const float* q32_dev, int nq, int dim, const float* shadow_de
  * crs_escalate_exact then makes every status-1 query exact on the same stream, with no host round trip: one more
  * sweep of the slab lists every row whose slab score is >= (k_out-th fp32 score so far) - eps_i (no row of the true
  * top-k can score lower), and the list is re-ranked in fp32; out_scores / out_ids of those queries are overwritten,
- * certified queries are left alone, and both kernels return at once when nothing is to do (so the call can sit in a
- * captured graph).  A list longer than `cap` rows leaves status[i] = 2: call again with a larger cap
+ * certified queries are left alone, and the one kernel's blocks all leave at once when nothing is to do (so the call can sit in a
+ * captured graph; the lists are re-ranked by the last block through the sweep -- release fence + counter, no spinning).  A list longer than `cap` rows leaves status[i] = 2: call again with a larger cap
  * (<= CRS_EXACT_MAX_CAP).  Workspace: crs_exact_workspace_bytes(nq, cap) bytes, written by crs_refine_f32_cert and
  * consumed by crs_escalate_exact (same nq, cap). */
 #define CRS_EXACT_MAX_CAP 13312
