@@ -122,3 +122,28 @@ def test_retrieval_benchmark_call_sequence(cuda, tmp_path):
     assert len(rag_pipeline.retrieve(questions[0])) <= 3
     # batched additive entry point agrees with the per-question loop
     assert rag_pipeline.retrieve_batch(questions) == [rag_pipeline.retrieve(q) for q in questions]
+
+
+def test_retrieve_batch_through_the_engine_on_a_tiny_store(cuda, tmp_path):
+    """>= batch_queries questions take the throughput engine (role lanes, encode groups capped by the call size, fused search
+    graphs) even over a handful of chunks: same dicts as the per-question loop, in order, for a call that does not fill its last
+    batch and for one that brings several batches."""
+    from rag import RAGPipeline
+    cfg = _rag_config(tmp_path)
+    cfg["vector_store"] = {"collection_name": "tiny"}
+    cfg["chunking"]["min_chunk_size"] = 50
+    rag_pipeline = RAGPipeline(cfg)
+    rag_pipeline.setup(StubModelInterface())
+    rag_pipeline.index_documents([p + "\n\n" + q for p, q in zip(PARAS, PARAS[1:] + PARAS[:1])], show_progress=False)
+    words = "retrieval generation quantization encoder attention relevance chunks model memory evidence passages index".split()
+    for n_q in (70, 200):
+        questions = [f"what about {words[i % len(words)]} and {words[(3 * i + 1) % len(words)]} number {i}" for i in range(n_q)]
+        batch = rag_pipeline.retrieve_batch(questions)
+        assert len(batch) == n_q
+        singles = [rag_pipeline.retrieve(q) for q in questions]
+        same = sum(1 for a, b in zip(batch, singles) if [c["chunk_id"] for c in a] == [c["chunk_id"] for c in b])
+        assert same >= n_q - 2          # (batched encoder forwards round differently in the last bit: a near-tie may swap)
+        for a, b in zip(batch, singles):
+            for ca, cb in zip(a, b):
+                if ca["chunk_id"] == cb["chunk_id"]:
+                    assert abs(ca["score"] - cb["score"]) < 1e-3
